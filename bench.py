@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sampler hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Msamples/s of forward + 3x backward, 2D cosine, multicell,
+N=16 C=16 H=W=256, P=2^20 points PER GPU (configs[1]; configs[4] = the same per-GPU work on
+8 GPUs, P=2^23 in total => weak scaling).  A *sample* is one (n,p) output location, all C channels.
+
+One step = one pass of the whole hot path over one batch of synthetic, HBM-resident inputs:
+    forward (K1) -> backward (K2: grad_input + grad_grid) -> backward_backward (K3, gOutInput absent)
+    -> fused third backward (K4 + the reference's extra K3), the three input-shaped gradients
+    accumulated into one buffer and, for N>1, summed over ranks with ONE RCCL all-reduce.
+All calls go through the C ABI (cosinesampler_amd.ops -> libcosine_sampler_hip.so).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the slowest stage kernel(s) (HIP-event time on
+the launch stream, algorithmic bytes from BASELINE.md section 3); `pipeline_roofline_frac` is the
+same ratio for the whole step.  `cpu_baseline` times this repo's pure-PyTorch composite of the op
+(oracle/composite.py, the same kind of path as the reference's test/grid_sampler.py) through
+torch.autograd on the host cores, on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(S, C, d, T):
+    """BASELINE.md section 3 / SURVEY.md 8(d): compulsory traffic, every tensor element once."""
+    return {
+        "forward": 4 * S * (d + C) + T,
+        "backward": 4 * S * (2 * d + C) + 2 * T,
+        "backward_backward": 4 * S * (3 * d + 2 * C) + 2 * T,
+        "bbb_fused": 4 * S * (3 * d + 3 * C) + 2 * T,
+    }
+
+
+def cpu_baseline(N, C, H, seconds_budget=20.0):
+    """The PyTorch-autograd CPU path on a bounded sample of the same workload."""
+    from oracle import composite
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def run(P):
+        g = torch.Generator().manual_seed(0)
+        cells = torch.rand(N, C, H, H, generator=g).requires_grad_(True)
+        xy = torch.rand(P, 2, generator=g) * 2 - 1
+        grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).requires_grad_(True)
+        gOut = torch.randn(N, C, 1, P, generator=g).requires_grad_(True)
+        cG = torch.randn(N, 1, P, 2, generator=g)
+        hG = torch.randn(N, 1, P, 2, generator=g)
+        hO = torch.randn(N, C, 1, P, generator=g)
+        t0 = time.perf_counter()
+        out = composite.grid_sample_nd(cells, grid, "cosine", True, True)
+        gI, gG = torch.autograd.grad(out, (cells, grid), gOut, create_graph=True)
+        bbI, bbG, bbO = torch.autograd.grad((gG * cG).sum(), (cells, grid, gOut), create_graph=True)
+        tI, tO = torch.autograd.grad((bbG * hG).sum() + (bbO * hO).sum(), (cells, gOut))
+        return time.perf_counter() - t0
+
+    P = 1 << 12
+    t = run(P)                     # warm-up + calibration
+    while t < seconds_budget / 8 and P < (1 << 18):
+        P *= 2
+        t = run(P)
+    t = min(t, run(P))
+    S = N * P
+    return {"value": S / t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "oracle/composite.py via torch.autograd (fwd + 3 grad levels), 2D cosine multicell "
+                      "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1 << 20, help="P per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    from cosinesampler_amd import multicell_offset, ops
+    from cosinesampler_amd.dist import all_reduce_grad_
+
+    N, C, H, P, d = 16, 16, 256, args.points, 2
+    S = N * P
+    T = 4 * N * C * H * H
+    pad, align, kern, mc = 0, True, 0, True
+
+    # synthetic inputs, each rank its own chunk of the global point set
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cells = torch.rand(N, C, H, H, generator=g).to(dev)
+    gp = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    xy = (torch.rand(P, 2, generator=gp) * 2 - 1).to(dev)
+    grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()          # PIXEL pattern
+    torch.manual_seed(1 + rank)
+    gOut = torch.randn(N, C, 1, P, device=dev)
+    hO = torch.randn(N, C, 1, P, device=dev)
+    cG = torch.randn(N, 1, P, 2, device=dev)
+    hG = torch.randn(N, 1, P, 2, device=dev)
+    off = multicell_offset(N, mc, dev)
+    acc = torch.zeros_like(cells)
+
+    stage_names = ["forward", "backward", "backward_backward", "bbb_fused"]
+    ev = []
+
+    def step(record):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        if record:
+            e[0].record()
+        out = ops.forward(cells, grid, off, pad, align, kern, mc)
+        if record:
+            e[1].record()
+        gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc)
+        if record:
+            e[2].record()
+        bbI, bbG, bbO = ops.backward_backward(None, cG, cells, grid, gOut, off, pad, align, False, kern, mc)
+        if record:
+            e[3].record()
+        tI, tO = ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, pad, align, kern, mc)
+        if record:
+            e[4].record()
+            ev.append(e)
+        torch.add(gI, bbI, out=acc)
+        acc.add_(tI)
+        all_reduce_grad_(acc)            # the single collective of a step (no-op at N=1)
+        return out, gG, bbG, bbO, tO
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) for i, nm in enumerate(stage_names)}
+    ab = algorithmic_bytes(S, C, d, T)
+    dom = max(stage_names, key=lambda k: stage_ms[k])
+    achieved = ab[dom] / (stage_ms[dom] * 1e-3)
+    ms_per_step = elapsed / args.steps * 1e3
+    total_bytes = sum(ab.values())
+
+    if rank == 0:
+        line = {
+            "metric": "Msamples/s fwd+3xbwd (2D cosine, C=16, 256^2 grid)",
+            "value": world * S * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "2D cosine multicell zeros align_corners N=16 C=16 H=W=256 P=%d per GPU: "
+                                   "forward + backward + backward_backward + fused third backward%s"
+                                   % (P, " + 1 RCCL all-reduce of grad_input (64 MiB)" if world > 1 else ""),
+                       "samples_per_step_per_gpu": S, "sharding": "points (P) across ranks"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]},
+            "pipeline_roofline_frac": total_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
+            "stages_ms": stage_ms,
+            "stages_frac": {k: ab[k] / (stage_ms[k] * 1e-3) / HBM_PEAK for k in stage_names},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, C, H)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""ctypes binding of libcosine_sampler_hip.so (include/cosine_sampler.h).
+
+There is no fallback: if the HIP library is missing or stale this raises, loudly.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_c_f = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_sz = ctypes.c_size_t
+
+# name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, workspace, bytes, stream
+_STAGES = {
+    "forward": 4,
+    "backward": 6,
+    "backward_backward": 9,
+    "backward_backward_backward": 8,
+    "bbb_fused": 9,
+}
+EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes"]
+           + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES])
+
+ABI_VERSION = 1
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "cosinesampler_amd: %s not found. Build it with `python -m cosinesampler_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % path)
+    lib = ctypes.CDLL(path)
+    lib.cs_abi_version.restype = _c_int
+    lib.cs_error_string.restype = ctypes.c_char_p
+    lib.cs_error_string.argtypes = [_c_int]
+    lib.cs_workspace_bytes.restype = _c_sz
+    lib.cs_workspace_bytes.argtypes = [_c_int, _c_int] + [_c_i64] * 6
+    if lib.cs_abi_version() != ABI_VERSION:
+        raise RuntimeError("cosinesampler_amd: %s has ABI %d, host code wants %d -- rebuild"
+                           % (path, lib.cs_abi_version(), ABI_VERSION))
+    for dim in (2, 3):
+        for stage, nptr in _STAGES.items():
+            fn = getattr(lib, "cs%dd_%s" % (dim, stage))
+            fn.restype = _c_int
+            fn.argtypes = [_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + [_c_f, _c_sz, _c_f]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cs_error_string(rc).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, rc))

@@ -1,0 +1,349 @@
+// cs_kernels_direct.cuh -- "direct" kernels: one lane per output sample (n,p), all C channels in
+// a register loop, node values gathered straight from the caller's NC[D]HW feature grid and the
+// grad_input scatter done with hardware fp32 atomics (global_atomic_add_f32).
+//
+// These are the general-purpose path: any C, any padding mode, any size.  They already remove
+// the reference's pure overheads (SURVEY section 7 "hard part 3"): no read-modify-write of
+// `output` through global memory (2d.cu:341-352), no atomics + 1 GiB memset for the
+// lane-private grad_grad_out (2d.cu:699-703, 2d.cpp:101), grad_out_grid read once per sample
+// (2d.cu:688-689), grad_grid stored once (2d.cu:501-505), and K4 + the extra K3 launch of
+// modules_2d.py:106-111 fused into one pass.
+//
+// Stage maths: SURVEY.md Appendix A; per-stage reference text:
+//   fwd  2d.cu:297-355   3d.cu:287-370
+//   bwd  2d.cu:406-506   3d.cu:428-583
+//   bb   2d.cu:569-716   3d.cu:652-868   (3D only: mixed second derivatives + gOutInput->grad_grid)
+//   bbb  2d.cu:774-890   3d.cu:932-1070  (pure second derivatives only)
+#pragma once
+#include "cs_math.cuh"
+
+namespace cs {
+
+struct Dims {
+    int N, C;
+    int size[3];    // x (W), y (H), z (D); size[2] = 1 for 2D
+    int64_t P;      // samples per n
+    int64_t S;      // N * P
+    int64_t vol;    // D*H*W elements of one (n,c) volume
+};
+
+template <int DIM>
+struct Sample {
+    static constexpr int NC = 1 << DIM;
+    int n;
+    int64_t p;
+    Axis ax[DIM];
+    int64_t node[NC];  // element offset inside one (n,c) volume, or -1 when zero-padded
+
+    template <int KERNEL, int ORDER>
+    __device__ __forceinline__ bool load(const float *grid, const float *offset, const Dims &d, const Flags &f,
+                                         int align) {
+        int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (s >= d.S) return false;
+        n = (int)(s / d.P);
+        p = s - (int64_t)n * d.P;
+        float off = offset[n];
+        const float *g = grid + s * DIM;
+        float gc[DIM];
+        if (DIM == 2) {
+            float2 v = *reinterpret_cast<const float2 *>(g);
+            gc[0] = v.x;
+            gc[1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) gc[j] = g[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) ax[j] = make_axis<KERNEL, ORDER>(gc[j], d.size[j], f, align, off);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            bool ok = true;
+            int64_t o = 0;
+            int64_t stride = 1;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                int idx = ax[j].lo + ((a >> j) & 1);
+                ok = ok && (idx >= 0) && (idx < d.size[j]);
+                o += (int64_t)idx * stride;
+                stride *= d.size[j];
+            }
+            node[a] = ok ? o : -1;
+        }
+        return true;
+    }
+
+    // W_a = prod_j w_j[bit_j(a)], multiplied in x, y, z order
+    __device__ __forceinline__ void weights(float (&W)[NC]) const {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            float w = ax[0].w[a & 1];
+#pragma unroll
+            for (int j = 1; j < DIM; ++j) w *= ax[j].w[(a >> j) & 1];
+            W[a] = w;
+        }
+    }
+    // product of the blending weights of every axis except j (and except k, if k >= 0)
+    __device__ __forceinline__ float others(int a, int j, int k = -1) const {
+        float w = 1.0f;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m)
+            if (m != j && m != k) w *= ax[m].w[(a >> m) & 1];
+        return w;
+    }
+    // F_j[a] = dW_a/dg_j
+    __device__ __forceinline__ float first(int a, int j) const {
+        float s = ((a >> j) & 1) ? ax[j].d1 : -ax[j].d1;
+        return s * others(a, j);
+    }
+    // H_jj[a] = d2W_a/dg_j^2
+    __device__ __forceinline__ float pure2(int a, int j) const {
+        float s = ((a >> j) & 1) ? -ax[j].d2 : ax[j].d2;
+        return s * others(a, j);
+    }
+    // H_jk[a] = d2W_a/dg_j dg_k, j != k
+    __device__ __forceinline__ float mixed2(int a, int j, int k) const {
+        float sj = ((a >> j) & 1) ? ax[j].d1 : -ax[j].d1;
+        float sk = ((a >> k) & 1) ? ax[k].d1 : -ax[k].d1;
+        return sj * sk * others(a, j, k);
+    }
+};
+
+template <int DIM>
+__device__ __forceinline__ void gather(const float *vol, const int64_t (&node)[1 << DIM], float (&v)[1 << DIM]) {
+#pragma unroll
+    for (int a = 0; a < (1 << DIM); ++a) v[a] = node[a] >= 0 ? vol[node[a]] : 0.0f;
+}
+
+// ----------------------------------------------------------------------------------------------
+// forward:  out[n,c,p] = sum_a W_a * input[n,c,q_a]
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL>
+__global__ __launch_bounds__(256) void direct_forward(const float *__restrict__ input, const float *__restrict__ grid,
+                                                      const float *__restrict__ offset, float *__restrict__ out,
+                                                      Dims d, Flags f) {
+    constexpr int NC = 1 << DIM;
+    Sample<DIM> sm;
+    // 2D forward: align_corners hard-wired to 1 in the reference (2d.cu:307-308); 3D honours it.
+    if (!sm.template load<KERNEL, 0>(grid, offset, d, f, DIM == 2 ? 1 : f.align)) return;
+    float W[NC];
+    sm.weights(W);
+    const float *in = input + (int64_t)sm.n * d.C * d.vol;
+    float *o = out + (int64_t)sm.n * d.C * d.P + sm.p;
+    for (int c = 0; c < d.C; ++c) {
+        float v[NC];
+        gather<DIM>(in, sm.node, v);
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if (sm.node[a] >= 0) acc = fmaf(v[a], W[a], acc);
+        *o = acc;
+        in += d.vol;
+        o += d.P;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward:  grad_input[n,c,q_a] += W_a * gOut ;  grad_grid[s,j] = sum_c gOut * sum_a F_j[a] * input[q_a]
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL>
+__global__ __launch_bounds__(256) void direct_backward(const float *__restrict__ gOut, const float *__restrict__ input,
+                                                       const float *__restrict__ grid, const float *__restrict__ offset,
+                                                       float *__restrict__ grad_input, float *__restrict__ grad_grid,
+                                                       Dims d, Flags f) {
+    constexpr int NC = 1 << DIM;
+    Sample<DIM> sm;
+    if (!sm.template load<KERNEL, 1>(grid, offset, d, f, f.align)) return;
+    float W[NC];
+    sm.weights(W);
+    // sum_a F_j[a] v_a = d1_j * sum_a (+/-) others(a,j) v_a : keep the signed sums, scale at the end
+    float oth[DIM][NC];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int a = 0; a < NC; ++a) oth[j][a] = ((a >> j) & 1) ? sm.others(a, j) : -sm.others(a, j);
+    float acc[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
+
+    const float *in = input + (int64_t)sm.n * d.C * d.vol;
+    float *gi = grad_input ? grad_input + (int64_t)sm.n * d.C * d.vol : nullptr;
+    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    for (int c = 0; c < d.C; ++c) {
+        float g = *go;
+        float v[NC];
+        gather<DIM>(in, sm.node, v);
+        if (gi) {
+#pragma unroll
+            for (int a = 0; a < NC; ++a)
+                if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], W[a] * g);
+            gi += d.vol;
+        }
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int a = 0; a < NC; ++a) t = fmaf(v[a], oth[j][a], t);
+            acc[j] = fmaf(t, g, acc[j]);
+        }
+        in += d.vol;
+        go += d.P;
+    }
+    float *gg = grad_grid + ((int64_t)sm.n * d.P + sm.p) * DIM;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) gg[j] = sm.ax[j].d1 * acc[j];
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward_backward (cotangents cI = gOutInput [nullable], cG = gOutGrid [nullable = 0]):
+//   D_a = sum_j F_j[a] cG_j
+//   gInput[n,c,q_a] += gOut * D_a
+//   ggOut[n,c,s]     = sum_a input[q_a] D_a  (+ sum_a cI[q_a] W_a)
+//   gGrid[s,j]       = sum_c gOut sum_a input[q_a] S_j[a]  (+ 3D: sum_c gOut sum_a cI[q_a] F_j[a])
+//   S_j[a] = H_jj[a] cG_j                       (2D: pure terms only, 2d.cu:705-706)
+//          = sum_k H_jk[a] cG_k                 (3D, 3d.cu:848-856)
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL>
+__global__ __launch_bounds__(256) void direct_backward_backward(
+    const float *__restrict__ cI, const float *__restrict__ cG, const float *__restrict__ input,
+    const float *__restrict__ grid, const float *__restrict__ gOut, const float *__restrict__ offset,
+    float *__restrict__ gInput, float *__restrict__ gGrid, float *__restrict__ ggOut, Dims d, Flags f) {
+    constexpr int NC = 1 << DIM;
+    constexpr bool FULL = (DIM == 3);
+    Sample<DIM> sm;
+    if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
+    float cg[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[((int64_t)sm.n * d.P + sm.p) * DIM + j] : 0.0f;
+
+    float W[NC], Dm[NC], F[DIM][NC], Sg[DIM][NC];
+    sm.weights(W);
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        float dsum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            F[j][a] = sm.first(a, j);
+            dsum = fmaf(F[j][a], cg[j], dsum);
+            float s = sm.pure2(a, j) * cg[j];
+            if (FULL) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k)
+                    if (k != j) s = fmaf(sm.mixed2(a, j, k), cg[k], s);
+            }
+            Sg[j][a] = s;
+        }
+        Dm[a] = dsum;
+    }
+    float acc[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
+
+    const float *in = input + (int64_t)sm.n * d.C * d.vol;
+    const float *ci = cI ? cI + (int64_t)sm.n * d.C * d.vol : nullptr;
+    float *gi = gInput + (int64_t)sm.n * d.C * d.vol;
+    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    for (int c = 0; c < d.C; ++c) {
+        float g = *go;
+        float v[NC];
+        gather<DIM>(in, sm.node, v);
+        float o = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) o = fmaf(v[a], Dm[a], o);
+        if (ci) {
+            float u[NC];
+            gather<DIM>(ci, sm.node, u);
+#pragma unroll
+            for (int a = 0; a < NC; ++a) o = fmaf(u[a], W[a], o);
+            if (FULL) {
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int a = 0; a < NC; ++a) t = fmaf(u[a], F[j][a], t);
+                    acc[j] = fmaf(t, g, acc[j]);
+                }
+            }
+            ci += d.vol;
+        }
+        *ggo = o;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int a = 0; a < NC; ++a) t = fmaf(v[a], Sg[j][a], t);
+            acc[j] = fmaf(t, g, acc[j]);
+        }
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], g * Dm[a]);
+        in += d.vol;
+        gi += d.vol;
+        go += d.P;
+        ggo += d.P;
+    }
+    float *gg = gGrid + ((int64_t)sm.n * d.P + sm.p) * DIM;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) gg[j] = acc[j];
+}
+
+// ----------------------------------------------------------------------------------------------
+// third backward, fused (cotangents hG = gOutgGrid [nullable = 0], hO = gOutggOut [nullable = 0]):
+//   E_a = sum_j H_jj[a] hG_j cG_j                (pure terms only, 2d.cu:833-834, 3d.cu:1008-1010)
+//   ggOut[n,c,s]      = sum_a input[q_a] E_a
+//   gInput[n,c,q_a]  += gOut * E_a + hO * D_a    (the D_a part is the reference's extra
+//                                                 backward_backward launch, modules_2d.py:109-111)
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL>
+__global__ __launch_bounds__(256) void direct_bbb_fused(
+    const float *__restrict__ input, const float *__restrict__ grid, const float *__restrict__ gOut,
+    const float *__restrict__ cG, const float *__restrict__ hG, const float *__restrict__ hO,
+    const float *__restrict__ offset, float *__restrict__ gInput, float *__restrict__ ggOut, Dims d, Flags f) {
+    constexpr int NC = 1 << DIM;
+    Sample<DIM> sm;
+    if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
+    float cg[DIM], hg[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        int64_t o = ((int64_t)sm.n * d.P + sm.p) * DIM + j;
+        cg[j] = cG ? cG[o] : 0.0f;
+        hg[j] = hG ? hG[o] : 0.0f;
+    }
+    float Dm[NC], Em[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        float dsum = 0.0f, esum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            dsum = fmaf(sm.first(a, j), cg[j], dsum);
+            esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+        }
+        Dm[a] = dsum;
+        Em[a] = esum;
+    }
+    const float *in = input + (int64_t)sm.n * d.C * d.vol;
+    float *gi = gInput + (int64_t)sm.n * d.C * d.vol;
+    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    const float *ho = hO ? hO + (int64_t)sm.n * d.C * d.P + sm.p : nullptr;
+    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    for (int c = 0; c < d.C; ++c) {
+        float g = *go;
+        float h = ho ? *ho : 0.0f;
+        float v[NC];
+        gather<DIM>(in, sm.node, v);
+        float o = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) o = fmaf(v[a], Em[a], o);
+        *ggo = o;
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], fmaf(g, Em[a], h * Dm[a]));
+        in += d.vol;
+        gi += d.vol;
+        go += d.P;
+        ggo += d.P;
+        if (ho) ho += d.P;
+    }
+}
+
+}  // namespace cs

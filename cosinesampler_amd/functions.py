@@ -1,0 +1,183 @@
+"""CosineSampler2d / CosineSampler3d: the reference's public autograd surface on the HIP kernels.
+
+    out = CosineSampler2d.apply(input, grid, padding_mode='zeros', align_corners=True,
+                                kernel='cosine', multicell=True)
+
+Same class names, positional argument order, strings and defaults as the reference
+(reference cosine_sampler_2d/modules_2d.py:20-44, cosine_sampler_3d/modules_3d.py:20-45), and the
+same three-level chain of Functions so that the op is differentiable to third order w.r.t.
+`input` and to second order w.r.t. `grid` (modules_2d.py:47-111):
+
+    level 1  CosineSampler{2,3}d           forward  -> ops.forward            (K1/K5)
+    level 2  _SamplerBackward              forward  -> ops.backward           (K2/K6)
+    level 3  _SamplerBackwardBackward      forward  -> ops.backward_backward  (K3/K7)
+                                           backward -> ops.bbb_fused          (K4/K8 + second K3/K7)
+
+What is deliberately NOT reproduced: the `.item()` host synchronisations
+(modules_2d.py:87,104; modules_3d.py:41,80,94) -- absent cotangents arrive as None
+(set_materialize_grads(False)) and go to the kernels as null pointers; the per-call CPU
+linspace + H2D copy of `offset` (modules_2d.py:24-27) -- built once per (N, device) with the same
+torch.linspace call so the bits match; the 3D 7-tuple early return (modules_3d.py:41-42).
+Third-order results match the reference exactly in what they contain: grads w.r.t. `input` and
+`gOut` only, no d/dgrid, `gOutgInput` ignored (modules_2d.py:111).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+
+def padding_mode_enum(padding_mode):
+    """reference modules_2d.py:4-10: anything that is not 'zeros'/'border' means reflection."""
+    if padding_mode == "zeros":
+        return 0
+    if padding_mode == "border":
+        return 1
+    return 2
+
+
+_KERNELS = {"cosine": 0, "bilinear": 1, "trilinear": 1, "linear": 1, "smooth-step": 2, "smoothstep": 2}
+
+
+def kernel_enum(kernel):
+    """reference modules_2d.py:12-18 / modules_3d.py:12-18.  'bilinear' (2D name) and 'trilinear'
+    (3D name) are accepted by both samplers, plus the aliases 'linear' and 'smoothstep'.
+    Unknown names give None, which the op layer rejects with a TypeError (the reference's pybind
+    call does the same)."""
+    return _KERNELS.get(kernel)
+
+
+class _Config(object):
+    __slots__ = ("pad", "align_corners", "kernel", "multicell")
+
+    def __init__(self, padding_mode, align_corners, kernel, multicell):
+        self.pad = padding_mode_enum(padding_mode)
+        self.align_corners = bool(align_corners)
+        self.kernel = kernel_enum(kernel)
+        self.multicell = bool(multicell)
+
+
+_offset_cache = {}
+
+
+def multicell_offset(N, multicell, device):
+    """offset[n] = linspace(0, 1-1/N, N) (multicell) or zeros (reference modules_2d.py:24-27),
+    computed by the same CPU torch.linspace call, cached on the device."""
+    device = torch.device(device)
+    key = (int(N), bool(multicell), device)
+    t = _offset_cache.get(key)
+    if t is None:
+        if multicell and N > 0:
+            t = torch.linspace(0, 1 - (1 / N), N)
+        else:
+            t = torch.zeros(N)
+        t = t.to(device)
+        _offset_cache[key] = t
+    return t
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multicell):
+    if input.dim() != dim + 2:
+        raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
+    cfg = _Config(padding_mode, align_corners, kernel, multicell)
+    offset = multicell_offset(input.shape[0], multicell, input.device)
+    output = ops.forward(input, grid, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell)
+    ctx.save_for_backward(input, grid)
+    ctx.offset = offset
+    ctx.cfg = cfg
+    return output
+
+
+def _backward(ctx, grad_out):
+    input, grid = ctx.saved_tensors
+    if grad_out is None:
+        return None, None, None, None, None, None
+    d_input, d_grid = _SamplerBackward.apply(input, grid, _c(grad_out), ctx.offset, ctx.cfg,
+                                             ctx.needs_input_grad[0])
+    return d_input, d_grid, None, None, None, None
+
+
+class CosineSampler2d(Function):
+    @staticmethod
+    def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
+        ctx.set_materialize_grads(False)
+        return _forward(ctx, 2, input, grid, padding_mode, align_corners, kernel, multicell)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _backward(ctx, grad_out)
+
+
+class CosineSampler3d(Function):
+    @staticmethod
+    def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
+        ctx.set_materialize_grads(False)
+        return _forward(ctx, 3, input, grid, padding_mode, align_corners, kernel, multicell)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _backward(ctx, grad_out)
+
+
+class _SamplerBackward(Function):
+    """(input, grid, gOut) -> (grad_input, grad_grid); reference CosineSamplerBackward,
+    modules_2d.py:47-74."""
+
+    @staticmethod
+    def forward(ctx, input, grid, gOut, offset, cfg, input_requires_grad):
+        ctx.set_materialize_grads(False)
+        ctx.offset = offset
+        ctx.cfg = cfg
+        grad_input, grad_grid = ops.backward(gOut, input, grid, offset, cfg.pad, cfg.align_corners,
+                                             bool(input_requires_grad), cfg.kernel, cfg.multicell)
+        ctx.save_for_backward(input, grid, gOut)
+        return grad_input, grad_grid
+
+    @staticmethod
+    def backward(ctx, gOutInput, gOutGrid):
+        input, grid, gOut = ctx.saved_tensors
+        if gOutInput is None and gOutGrid is None:
+            return None, None, None, None, None, None
+        gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
+                                                              ctx.offset, ctx.cfg)
+        return gInput, gGrid, ggOut, None, None, None
+
+
+class _SamplerBackwardBackward(Function):
+    """(input, grid, gOut, gOutInput, gOutGrid) -> (gInput, gGrid, ggOut); reference
+    CosineSamplerBackwardBackward, modules_2d.py:76-111."""
+
+    @staticmethod
+    def forward(ctx, input, grid, gOut, gOutInput, gOutGrid, offset, cfg):
+        ctx.set_materialize_grads(False)
+        ctx.offset = offset
+        ctx.cfg = cfg
+        gInput, gGrid, ggOut = ops.backward_backward(gOutInput, gOutGrid, input, grid, gOut, offset, cfg.pad,
+                                                     cfg.align_corners, gOutInput is not None, cfg.kernel,
+                                                     cfg.multicell)
+        ctx.has_cG = gOutGrid is not None
+        if gOutGrid is None:
+            ctx.save_for_backward(input, grid, gOut)
+        else:
+            ctx.save_for_backward(input, grid, gOut, gOutGrid)
+        return gInput, gGrid, ggOut
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gOutgInput, gOutgGrid, gOutggOut):
+        # gOutgInput is ignored, exactly as in the reference (modules_2d.py:106-111).
+        if ctx.has_cG:
+            input, grid, gOut, gOutGrid = ctx.saved_tensors
+        else:
+            (input, grid, gOut), gOutGrid = ctx.saved_tensors, None
+        if gOutgGrid is None and gOutggOut is None:
+            return None, None, None, None, None, None, None
+        cfg = ctx.cfg
+        gInput, ggOut = ops.bbb_fused(input, grid, gOut, gOutGrid, _c(gOutgGrid), _c(gOutggOut), ctx.offset,
+                                      cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell)
+        return gInput, None, ggOut, None, None, None, None

@@ -1,0 +1,166 @@
+"""Stage-level ops on torch CUDA tensors -> C ABI -> HIP kernels.
+
+Mirror of the reference's pybind module `_cosine_2d` / `_cosine_3d`
+(reference cosine_sampler_2d/csrc/cosine_sampler_2d.cpp:47-135, cosine_sampler_3d/csrc/cosine_sampler_3d.cpp:50-138):
+same four functions, same argument order and meaning, one module for both dimensionalities
+(dispatch on input.dim()), plus `bbb_fused` = everything CosineSamplerBackwardBackward.backward
+does (reference modules_2d.py:98-111) in one launch.
+
+PyTorch is used for device memory and the current stream only.  Differences from the reference,
+all deliberate: outputs are torch.empty (the kernels define every element, nothing relies on
+zeros_like); shapes/dtypes are validated (the reference has no checks beyond CUDA+contiguous);
+no host synchronisation anywhere.
+"""
+import torch
+
+from . import _lib
+
+
+def _check(t, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)         # reference 2d.cpp:4
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)            # reference 2d.cpp:5
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s): only the fp32 path is built" % (name, t.dtype))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _problem(input, grid):
+    _check(input, "input")
+    _check(grid, "grid")
+    dim = input.dim() - 2
+    if dim not in (2, 3):
+        raise RuntimeError("input must be (N,C,H,W) or (N,C,D,H,W), got %s" % (tuple(input.shape),))
+    if grid.dim() != dim + 2 or grid.shape[-1] != dim or grid.shape[0] != input.shape[0]:
+        raise RuntimeError("grid must be (N,%s%d) with N=%d, got %s"
+                           % ("Ho,Wo," if dim == 2 else "Do,Ho,Wo,", dim, input.shape[0], tuple(grid.shape)))
+    if grid.device != input.device:
+        raise RuntimeError("input and grid must be on the same device")
+    P = 1
+    for s in grid.shape[1:-1]:
+        P *= int(s)
+    return dim, [int(s) for s in input.shape], P
+
+
+def _same(t, like_shape, name, device):
+    _check(t, name)
+    if tuple(t.shape) != tuple(like_shape):
+        raise RuntimeError("%s must have shape %s, got %s" % (name, tuple(like_shape), tuple(t.shape)))
+    if t.device != device:
+        raise RuntimeError("%s must be on %s" % (name, device))
+
+
+def _offset_ok(offset, N, device):
+    _check(offset, "offset")
+    if offset.numel() != N or offset.device != device:
+        raise RuntimeError("offset must hold N=%d floats on %s" % (N, device))
+
+
+def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device):
+    if kernel not in (0, 1, 2):
+        # the reference's kernel_enum returns None for unknown names and pybind then rejects it
+        raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), got %r" % (kernel,))
+    lib = _lib.load()
+    fn = getattr(lib, "cs%dd_%s" % (dim, stage))
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
+                None, 0, stream)
+    _lib.check(rc, "cs%dd_%s" % (dim, stage))
+
+
+def out_shape(input, grid):
+    return tuple(input.shape[:2]) + tuple(grid.shape[1:-1])
+
+
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell):
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    output = torch.empty(out_shape(input, grid), dtype=input.dtype, device=input.device)
+    _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P,
+          padding_mode, align_corners, kernel, multicell, input.device)
+    return output
+
+
+def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell):
+    """-> (grad_input | None, grad_grid); grad_input is None when input_requires_grad is False
+    (the reference returns an undefined Tensor, 2d.cpp:73-79)."""
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    grad_input = torch.empty_like(input) if input_requires_grad else None
+    grad_grid = torch.empty_like(grid)
+    _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
+                            _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+    return grad_input, grad_grid
+
+
+def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
+                      input_requires_grad, kernel, multicell):
+    """-> (grad_input, grad_grid, grad_grad_out).  grad_out_input is only read when
+    input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros)."""
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    if input_requires_grad:
+        _same(grad_out_input, input.shape, "grad_out_input", input.device)
+    else:
+        grad_out_input = None
+    if grad_out_grid is not None:
+        _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
+    grad_input = torch.empty_like(input)
+    grad_grid = torch.empty_like(grid)
+    grad_grad_out = torch.empty_like(grad_output)
+    _call("backward_backward", dim,
+          [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
+           _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+    return grad_input, grad_grid, grad_grad_out
+
+
+def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, padding_mode,
+                               align_corners, input_requires_grad, kernel, multicell):
+    """-> (grad_input, grad_grad_out).  `input_requires_grad` is accepted and ignored, as in the
+    reference kernel (2d.cu:736)."""
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
+    _same(grad_out_ggrid, grid.shape, "grad_out_ggrid", input.device)
+    grad_input = torch.empty_like(input)
+    grad_grad_out = torch.empty_like(grad_output)
+    _call("backward_backward_backward", dim,
+          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
+           _ptr(grad_input), _ptr(grad_grad_out)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+    return grad_input, grad_grad_out
+
+
+def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
+              align_corners, kernel, multicell):
+    """-> (grad_input, grad_grad_out) of the whole third backward (reference modules_2d.py:98-111):
+    grad_input = K4.gInput + K3(gOut := grad_out_ggout, gOutInput := ones).gInput in one pass.
+    grad_out_grid / grad_out_ggrid / grad_out_ggout may each be None (= zeros)."""
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
+        if t is not None:
+            _same(t, grid.shape, nm, input.device)
+    if grad_out_ggout is not None:
+        _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device)
+    grad_input = torch.empty_like(input)
+    grad_grad_out = torch.empty_like(grad_output)
+    _call("bbb_fused", dim,
+          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
+           _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+    return grad_input, grad_grad_out

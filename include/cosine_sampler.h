@@ -1,0 +1,143 @@
+/*
+ * cosine_sampler.h -- C ABI of libcosine_sampler_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of NamGyuKang/CosineSampler: the four native entry points
+ * per dimensionality that the reference exposes through pybind11 as `_cosine_2d` / `_cosine_3d`
+ *   reference cosine_sampler_2d/csrc/cosine_sampler_2d.cpp:130-135   (2D)
+ *   reference cosine_sampler_3d/csrc/cosine_sampler_3d.cpp:133-138   (3D)
+ * restated as plain C: raw device pointers, explicit sizes, integer flags, a HIP stream handle.
+ * No C++ or torch types cross this boundary, nothing is allocated, freed or synchronised inside,
+ * every call only ENQUEUES work on `stream` (graph-capturable).
+ *
+ * Conventions
+ *   - All tensors are contiguous fp32 in device memory (the reference's CHECK_CUDA /
+ *     CHECK_CONTIGUOUS, 2d.cpp:4-6).  fp16/fp64 are not built yet: return CS_ERR_UNSUPPORTED.
+ *   - 2D: input (N,C,H,W), grid (N,Ho,Wo,2), out/gOut (N,C,Ho,Wo);  P = Ho*Wo.
+ *     3D: input (N,C,D,H,W), grid (N,Do,Ho,Wo,3), out/gOut (N,C,Do,Ho,Wo);  P = Do*Ho*Wo.
+ *     grid[...,0] addresses W, [...,1] H, [...,2] D, each in [-1,1].
+ *   - `offset` = N floats, the per-cell "multicell" shift the reference's Python builds with
+ *     torch.linspace(0, 1-1/N, N) (modules_2d.py:24-27); zeros when multicell == 0.
+ *   - padding_mode: 0 zeros, 1 border, 2 reflection (modules_2d.py:4-10)
+ *     kernel:       0 cosine, 1 linear, 2 smoothstep (modules_2d.py:12-18)
+ *   - Outputs are caller-allocated and need NO pre-zeroing: every element of every output is
+ *     defined by the call (the reference needs zeros_like for grad_input / ggOut, 2d.cpp:75,99-101).
+ *   - Nullable pointers replace the reference's `input_requires_grad` flags; see each function.
+ *   - `workspace`: scratch device memory, at least cs_workspace_bytes(...) bytes, 256-byte
+ *     aligned, owned by the caller, contents undefined before and after.  May be NULL when the
+ *     query returns 0.
+ *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
+ *     hipError_t from the launch.  cs_error_string() describes either.
+ *   - Thread-safe and re-entrant: the library keeps no mutable global state.
+ */
+#ifndef COSINE_SAMPLER_H
+#define COSINE_SAMPLER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+
+enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
+enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
+enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
+/* stage ids for cs_workspace_bytes */
+enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
+
+int cs_abi_version(void);
+const char *cs_error_string(int code);
+
+/* Scratch bytes stage `stage` needs for this problem.  dim = 2 or 3; D is ignored for dim 2. */
+size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
+
+/* ---- 2D -------------------------------------------------------------------------------- */
+
+/* Replaces `_cosine_2d.forward` (2d.cpp:47-62 -> launch_cosine_sampler_forward_kernel, 2d.cu:897).
+ * NB the reference 2D forward ignores align_corners (2d.cu:307-308); so does this, for parity. */
+int cs2d_forward(const float *input, const float *grid, const float *offset, float *output,
+                 int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                 int padding_mode, int align_corners, int kernel, int multicell,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces `_cosine_2d.backward` (2d.cpp:64-85 -> 2d.cu:938).
+ * grad_input == NULL  <=>  input_requires_grad == false (2d.cpp:73-79). */
+int cs2d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
+                  float *grad_input /* nullable */, float *grad_grid,
+                  int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                  int padding_mode, int align_corners, int kernel, int multicell,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces `_cosine_2d.backward_backward` (2d.cpp:87-106 -> 2d.cu:990).
+ * grad_out_input == NULL <=> input_requires_grad == false (modules_2d.py:87-89).
+ * grad_out_grid == NULL is read as all zeros. */
+int cs2d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
+                           const float *input, const float *grid, const float *grad_output, const float *offset,
+                           float *grad_input, float *grad_grid, float *grad_grad_out,
+                           int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                           int padding_mode, int align_corners, int kernel, int multicell,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces `_cosine_2d.backward_backward_backward` (2d.cpp:108-127 -> 2d.cu:1058). */
+int cs2d_backward_backward_backward(const float *input, const float *grid, const float *grad_output,
+                                    const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
+                                    float *grad_input, float *grad_grad_out,
+                                    int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                                    int padding_mode, int align_corners, int kernel, int multicell,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole of CosineSamplerBackwardBackward.backward (modules_2d.py:98-111) in one pass: the
+ * kernel above PLUS the reference's second backward_backward launch with gOut := grad_out_ggout,
+ * gOutInput := ones, of which only grad_input is kept and added.
+ *   grad_input[n,c,q]   = sum_s  gOut*E_a + grad_out_ggout*D_a
+ *   grad_grad_out[n,c,s] = sum_a input[q_a]*E_a
+ * grad_out_ggrid == NULL and/or grad_out_ggout == NULL are read as all zeros. */
+int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_output,
+                   const float *grad_out_grid, const float *grad_out_ggrid /* nullable */,
+                   const float *grad_out_ggout /* nullable */, const float *offset,
+                   float *grad_input, float *grad_grad_out,
+                   int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                   int padding_mode, int align_corners, int kernel, int multicell,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- 3D: same contracts; 3d.cpp:50-131 -> 3d.cu:1073,1115,1167,1241; modules_3d.py:87-100 --- */
+
+int cs3d_forward(const float *input, const float *grid, const float *offset, float *output,
+                 int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                 int padding_mode, int align_corners, int kernel, int multicell,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+int cs3d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
+                  float *grad_input /* nullable */, float *grad_grid,
+                  int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                  int padding_mode, int align_corners, int kernel, int multicell,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+int cs3d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
+                           const float *input, const float *grid, const float *grad_output, const float *offset,
+                           float *grad_input, float *grad_grid, float *grad_grad_out,
+                           int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                           int padding_mode, int align_corners, int kernel, int multicell,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+int cs3d_backward_backward_backward(const float *input, const float *grid, const float *grad_output,
+                                    const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
+                                    float *grad_input, float *grad_grad_out,
+                                    int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                                    int padding_mode, int align_corners, int kernel, int multicell,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
+int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_output,
+                   const float *grad_out_grid, const float *grad_out_ggrid /* nullable */,
+                   const float *grad_out_ggout /* nullable */, const float *offset,
+                   float *grad_input, float *grad_grad_out,
+                   int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                   int padding_mode, int align_corners, int kernel, int multicell,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSINE_SAMPLER_H */

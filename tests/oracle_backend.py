@@ -1,0 +1,45 @@
+"""TEST-ONLY: swap cosinesampler_amd.ops for the CPU oracle so that the host logic (the autograd
+Function chain, None handling, sharding helpers) can be exercised without a GPU.  The product
+never imports this; on a GPU box the parity tests call the real ops and compare with the oracle."""
+import torch
+
+from oracle import cs_oracle
+
+
+def _f(t):
+    return None if t is None else t.contiguous()
+
+
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell):
+    if kernel not in (0, 1, 2):
+        raise TypeError("kernel enum")
+    return cs_oracle.forward(_f(input), _f(grid), offset, padding_mode, align_corners, kernel, multicell)
+
+
+def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell):
+    return cs_oracle.backward(_f(grad_output), _f(input), _f(grid), offset, padding_mode, align_corners,
+                              input_requires_grad, kernel, multicell)
+
+
+def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
+                      input_requires_grad, kernel, multicell):
+    if grad_out_grid is None:
+        grad_out_grid = torch.zeros_like(grid)
+    return cs_oracle.backward_backward(_f(grad_out_input), _f(grad_out_grid), _f(input), _f(grid), _f(grad_output),
+                                       offset, padding_mode, align_corners, input_requires_grad, kernel, multicell)
+
+
+def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
+              align_corners, kernel, multicell):
+    z = torch.zeros_like(grid)
+    return cs_oracle.bbb_fused(_f(input), _f(grid), _f(grad_output),
+                               z if grad_out_grid is None else _f(grad_out_grid),
+                               z if grad_out_ggrid is None else _f(grad_out_ggrid),
+                               torch.zeros_like(grad_output) if grad_out_ggout is None else _f(grad_out_ggout),
+                               offset, padding_mode, align_corners, kernel, multicell)
+
+
+def install(monkeypatch):
+    from cosinesampler_amd import ops
+    for name in ("forward", "backward", "backward_backward", "bbb_fused"):
+        monkeypatch.setattr(ops, name, globals()[name])

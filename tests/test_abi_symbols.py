@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library builds (hipcc cross-compiles gfx950 without a GPU), loads, and exports
+every symbol include/cosine_sampler.h declares.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+from cosinesampler_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "cosine_sampler.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cs[0-9a-z_]*)\s*\(", text)))
+
+
+def test_header_declares_the_reference_entry_points():
+    names = declared_functions()
+    for dim in (2, 3):
+        for stage in ("forward", "backward", "backward_backward", "backward_backward_backward", "bbb_fused"):
+            assert "cs%dd_%s" % (dim, stage) in names
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    lib.cs_abi_version.restype = ctypes.c_int
+    assert lib.cs_abi_version() == _lib.ABI_VERSION
+
+
+def test_loader_binds_and_reports_errors_without_gpu():
+    lib = _lib.load()
+    assert lib.cs_error_string(0) == b"ok"
+    assert b"invalid" in lib.cs_error_string(-1)
+    assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20) >= 0
+    # argument validation happens before any device work: callable without a GPU
+    rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, 0, None)
+    assert rc == -1  # padding_mode 7 is not a mode
+
+
+def test_code_object_is_gfx950():
+    data = open(build.LIB, "rb").read()
+    assert b"gfx950" in data

@@ -1,0 +1,91 @@
+"""CPU, world_size 2, gloo: the sample-sharded path.  Each rank runs the op on its slice of the
+points (kernels replaced by the CPU oracle), grad_input partial sums meet in ONE all-reduce, and
+everything must equal the unsharded run.  The GPU job uses backend "nccl" (= RCCL) instead."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cosinesampler_amd.dist import point_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_point_range_partitions_exactly():
+    for P in (0, 1, 7, 8, 1000, 1 << 20):
+        for w in (1, 2, 3, 8):
+            spans = [point_range(P, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == P
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, d, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_backend
+        from cosinesampler_amd import CosineSampler2d, CosineSampler3d, ops
+        from cosinesampler_amd.dist import all_reduce_grad_, gather_points, shard_grid
+        for name in ("forward", "backward", "backward_backward", "bbb_fused"):
+            setattr(ops, name, getattr(oracle_backend, name))
+        Fn = CosineSampler2d if d == 2 else CosineSampler3d
+
+        g = torch.Generator().manual_seed(123)     # same data on every rank
+        N, C, S, P = 3, 4, 8, 101                  # P odd: uneven shards
+        cells = torch.rand((N, C) + (S,) * d, generator=g)
+        grid = torch.rand((N,) + (1,) * (d - 1) + (P, d), generator=g) * 2 - 1
+        wts = torch.randn((N, C) + (1,) * (d - 1) + (P,), generator=g)
+
+        def loss_and_grad(cells_, grid_, w_):
+            cells_ = cells_.clone().requires_grad_(True)
+            grid_ = grid_.clone().requires_grad_(True)
+            out = Fn.apply(cells_, grid_, "zeros", True, "cosine", True)
+            (gg,) = torch.autograd.grad((out * w_).sum(), grid_, create_graph=True)
+            loss = (out * w_).sum() + (gg ** 2).sum()          # touches fwd, bwd, bb
+            (gc,) = torch.autograd.grad(loss, cells_)
+            return out.detach(), gc
+
+        full_out, full_gc = loss_and_grad(cells, grid, wts)
+        lo, hi = point_range(P, rank, world)
+        loc_grid = shard_grid(grid, rank, world)
+        loc_out, loc_gc = loss_and_grad(cells, loc_grid, wts[..., lo:hi].contiguous())
+        all_reduce_grad_(loc_gc)                                 # the one collective
+        out = gather_points(loc_out)
+        ok = (torch.allclose(out, full_out, rtol=0, atol=0)
+              and float((loc_gc - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max()))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_sharded_equals_unsharded_world2(d):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, True), (1, True)]

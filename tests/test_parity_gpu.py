@@ -1,0 +1,279 @@
+"""GPU (MI355X): the HIP kernels, called through the C ABI, against
+  * the CPU oracle (oracle/cs_oracle.c) on the same seeded inputs,
+  * the golden vectors from the reference's ground truth,
+  * torch.nn.functional.grid_sample for the linear kernel (bit-exact forward),
+  * size-independent properties at BASELINE.json's full sizes.
+Tolerance: max|a-b|/max|b| <= 1e-5 per tensor (helpers.REL_TOL; north_star's "within 1e-5 fp32")."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cosinesampler_amd import CosineSampler2d, CosineSampler3d, _lib, multicell_offset, ops
+from helpers import (KERNEL_ENUM, PAD, PIXEL_KEYS_2D, PIXEL_KEYS_3D, assert_close, axis_only, load, offsets,
+                     parse_stage_name, pixel_pipeline, rel_err, stage_fixtures)
+from oracle import cs_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_native_library_is_the_loaded_one():
+    lib = _lib.load()
+    assert lib.cs_abi_version() == 1
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def _g(t):
+    return None if t is None else t.to(DEV)
+
+
+def _case(d, N, C, sp, P, seed, spread=1.3):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.rand((N, C) + tuple(sp), generator=g)
+    grid = torch.rand((N,) + (1,) * (d - 1) + (P, d), generator=g) * (2 * spread) - spread
+    if P >= 4:  # exact corners and centre
+        grid.view(N, P, d)[:, 0] = -1.0
+        grid.view(N, P, d)[:, 1] = 1.0
+        grid.view(N, P, d)[:, 2] = 0.0
+    oshape = (N, C) + (1,) * (d - 1) + (P,)
+    t = dict(inp=inp, grid=grid, gOut=torch.randn(oshape, generator=g), cI=torch.randn(inp.shape, generator=g),
+             cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g),
+             hO=torch.randn(oshape, generator=g))
+    return t
+
+
+def _run_all_stages(mod, t, off, pad, align, ke, mc, dev):
+    """mod = ops (GPU, through the C ABI) or cs_oracle (CPU).  Same call sequence for both."""
+    x = {k: v.to(dev) for k, v in t.items()}
+    off = off.to(dev)
+    r = {}
+    r["out"] = mod.forward(x["inp"], x["grid"], off, pad, align, ke, mc)
+    r["gI"], r["gG"] = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, True, ke, mc)
+    none_gi, gG2 = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, False, ke, mc)
+    assert none_gi is None
+    r["gG_noinput"] = gG2
+    r["bbI"], r["bbG"], r["bbO"] = mod.backward_backward(x["cI"], x["cG"], x["inp"], x["grid"], x["gOut"], off, pad,
+                                                         align, True, ke, mc)
+    r["bbI0"], r["bbG0"], r["bbO0"] = mod.backward_backward(None, x["cG"], x["inp"], x["grid"], x["gOut"], off,
+                                                            pad, align, False, ke, mc)
+    r["k4I"], r["k4O"] = mod.backward_backward_backward(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], off, pad,
+                                                        align, True, ke, mc)
+    r["fI"], r["fO"] = mod.bbb_fused(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], off, pad, align, ke,
+                                     mc)
+    return r
+
+
+CASES = []
+for _d in (2, 3):
+    for _kernel in (0, 1, 2):
+        for _mc in (True, False):
+            for _pad in (0, 1, 2):
+                for _align in (True, False):
+                    CASES.append((_d, _kernel, _mc, _pad, _align))
+
+
+@pytest.mark.parametrize("d,ke,mc,pad,align", CASES)
+def test_every_stage_matches_cpu_oracle(d, ke, mc, pad, align):
+    N, C, P = 3, 5, 777                                # ragged: not a multiple of the block size
+    sp = (9, 14) if d == 2 else (5, 7, 6)
+    t = _case(d, N, C, sp, P, seed=100 * d + 10 * ke + pad)
+    off = offsets(N, mc)
+    want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
+    got = _run_all_stages(ops, t, off, pad, align, ke, mc, DEV)
+    torch.cuda.synchronize()
+    for k in want:
+        assert_close(got[k], want[k], "d=%d kernel=%d mc=%s pad=%d align=%s: %s" % (d, ke, mc, pad, align, k))
+
+
+@pytest.mark.parametrize("name", stage_fixtures())
+def test_stage_golden_vectors(name):
+    d, kernel, mc = parse_stage_name(name)
+    fx = load(name)
+    ke = KERNEL_ENUM[kernel]
+    N = fx["cells"].shape[0]
+    off = multicell_offset(N, mc, DEV)
+    cells, grid, gOut = _g(fx["cells"]), _g(fx["grid"]), _g(fx["gOut"])
+    out = ops.forward(cells, grid, off, 0, True, ke, mc)
+    assert_close(out, fx["out"], name + " out")
+    gI, gG = ops.backward(gOut, cells, grid, off, 0, True, True, ke, mc)
+    assert_close(gI, fx["gI"], name + " gI")
+    assert_close(gG, fx["gG"], name + " gG")
+    bbI, bbG, bbO = ops.backward_backward(_g(fx["cI"]), _g(fx["cG"]), cells, grid, gOut, off, 0, True, True, ke, mc)
+    assert_close(bbI, fx["bbI"], name + " bbI")
+    assert_close(bbO, fx["bbO"], name + " bbO")
+    if d == 3:
+        assert_close(bbG, fx["bbG"], name + " bbG")
+    for j in range(d):
+        cGj, hGj = _g(axis_only(fx["cG"], j)), _g(axis_only(fx["hG"], j))
+        bI, bG, bO = ops.backward_backward(None, cGj, cells, grid, gOut, off, 0, True, False, ke, mc)
+        assert_close(bI, fx["bbj%d_I" % j], name + " bbj I")
+        assert_close(bO, fx["bbj%d_O" % j], name + " bbj O")
+        ref = fx["bbj%d_G" % j]
+        den = max(float(ref.abs().max()), 1e-30)
+        assert float((bG.cpu()[..., j] - ref[..., j]).abs().max()) / den <= 1e-5, name + " bbj G_j"
+        tI, tO = ops.bbb_fused(cells, grid, gOut, cGj, hGj, _g(fx["hO"]), off, 0, True, ke, mc)
+        assert_close(tI, fx["bbbj%d_I" % j], name + " bbbj I")
+        assert_close(tO, fx["bbbj%d_O" % j], name + " bbbj O")
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_pixel_pipeline_golden(d):
+    """End to end through torch.autograd on the GPU, the way the reference tests use the op."""
+    fx = load("pixel_%dd" % d)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    got = pixel_pipeline(lambda cells, grid: Fn.apply(cells, grid, "zeros", True, "cosine", True), fx, d, DEV)
+    for k in (PIXEL_KEYS_2D if d == 2 else PIXEL_KEYS_3D):
+        assert_close(got[k], fx[k], "pixel_%dd %s" % (d, k))
+    atol = 1e-5 * float(fx["dloss"].abs().max())
+    torch.testing.assert_close(got["dloss"], fx["dloss"], rtol=1e-4, atol=atol)  # test_2d.py:244
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("shape", [(1, 1, 32, 32, 1024), (4, 3, 17, 29, 5000)])
+def test_linear_forward_bit_matches_torch_grid_sample_2d(pad, shape):
+    """BASELINE.json configs[0] + north_star: 'linear kernel bit-matches torch.grid_sample'."""
+    N, C, H, W, P = shape
+    g = torch.Generator().manual_seed(7)
+    inp = torch.rand(N, C, H, W, generator=g).to(DEV)
+    grid = (torch.rand(N, 1, P, 2, generator=g) * 2.6 - 1.3).to(DEV)
+    want = F.grid_sample(inp, grid, mode="bilinear", padding_mode=pad, align_corners=True)
+    got = CosineSampler2d.apply(inp, grid, pad, True, "bilinear", False)
+    assert torch.equal(got, want), "max diff %g" % float((got - want).abs().max())
+    # first backward: same maths, float atomics in both -> tolerance, not bits
+    inp.requires_grad_(True)
+    grid.requires_grad_(True)
+    gOut = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    wI, wG = torch.autograd.grad(F.grid_sample(inp, grid, mode="bilinear", padding_mode=pad, align_corners=True),
+                                 (inp, grid), gOut)
+    gI, gG = torch.autograd.grad(CosineSampler2d.apply(inp, grid, pad, True, "bilinear", False), (inp, grid), gOut)
+    assert rel_err(gI, wI) <= 1e-5 and rel_err(gG, wG) <= 1e-5
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("align", [True, False])
+def test_linear_forward_bit_matches_torch_grid_sample_3d(pad, align):
+    N, C, D, H, W, P = 2, 3, 9, 11, 10, 4001
+    g = torch.Generator().manual_seed(8)
+    inp = torch.rand(N, C, D, H, W, generator=g).to(DEV)
+    grid = (torch.rand(N, 1, 1, P, 3, generator=g) * 2.6 - 1.3).to(DEV)
+    want = F.grid_sample(inp, grid, mode="bilinear", padding_mode=pad, align_corners=align)
+    got = CosineSampler3d.apply(inp, grid, pad, align, "trilinear", False)
+    assert torch.equal(got, want), "max diff %g" % float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_edge_shapes(d):
+    sp = (6, 5) if d == 2 else (4, 6, 5)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    # empty point set, single point, single channel, far out-of-range points
+    for N, C, P in ((2, 3, 0), (1, 1, 1), (2, 1, 65), (1, 7, 256)):
+        inp = torch.rand((N, C) + sp, device=DEV, requires_grad=True)
+        grid = (torch.rand((N,) + (1,) * (d - 1) + (P, d), device=DEV) * 8 - 4).requires_grad_(True)
+        out = Fn.apply(inp, grid, "zeros", True, "cosine", True)
+        assert out.shape == (N, C) + (1,) * (d - 1) + (P,)
+        gI, gG = torch.autograd.grad(out.sum(), (inp, grid), create_graph=True)
+        assert gI.shape == inp.shape and gG.shape == grid.shape
+        assert torch.isfinite(out).all() and torch.isfinite(gI).all() and torch.isfinite(gG).all()
+        if P:
+            t = dict(inp=inp.detach().cpu(), grid=grid.detach().cpu())
+            want = cs_oracle.forward(t["inp"], t["grid"], offsets(N, True), 0, True, 0, True)
+            assert_close(out, want, "edge N=%d C=%d P=%d" % (N, C, P))
+    # non-contiguous / wrong dtype inputs are rejected, not silently copied
+    inp = torch.rand((2, 3) + sp, device=DEV)
+    grid = torch.rand((2,) + (1,) * (d - 1) + (9, d), device=DEV)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        Fn.apply(inp.transpose(-1, -2), grid)
+    with pytest.raises(RuntimeError, match="float32"):
+        Fn.apply(inp.double(), grid.double())
+    with pytest.raises(RuntimeError, match="grid must be"):
+        Fn.apply(inp, grid[:1])
+
+
+def _full_size_inputs():
+    # BASELINE.json configs[1]: 2D cosine, multicell, N=16 C=16 H=W=256 P=2^20
+    torch.manual_seed(0)
+    N, C, H, P = 16, 16, 256, 1 << 20
+    inp = torch.rand(N, C, H, H, device=DEV)
+    xy = torch.rand(P, 2, device=DEV) * 2 - 1
+    grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    return inp, grid
+
+
+def test_full_size_2d_properties():
+    """At full size the oracle is too slow; check identities that do not depend on size:
+       partition of unity, linearity, and the adjoint identities linking each stage pair."""
+    inp, grid = _full_size_inputs()
+    N, C, H, P = 16, 16, 256, 1 << 20
+    off = multicell_offset(N, True, DEV)
+    args = (0, True, 0, True)
+    # 1. weights sum to one: a constant field samples to the constant (all nodes in range here)
+    ones = torch.ones_like(inp)
+    out1 = ops.forward(ones, grid, off, *args)
+    assert float((out1 - 1).abs().max()) <= 2e-6
+    # 2. linearity in input
+    inp2 = torch.rand_like(inp)
+    a = ops.forward(inp, grid, off, *args)
+    b = ops.forward(inp2, grid, off, *args)
+    ab = ops.forward(inp * 0.5 + inp2, grid, off, *args)
+    assert rel_err(ab, a * 0.5 + b) <= 1e-6
+    del ab, b, out1, ones
+    # 3. <out, gOut> == <input, grad_input>   (backward is the adjoint of forward)
+    gOut = torch.randn(N, C, 1, P, device=DEV)
+    gI, gG = ops.backward(gOut, inp, grid, off, 0, True, True, 0, True)
+    lhs = float((a.double() * gOut.double()).sum())
+    rhs = float((inp.double() * gI.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0)
+    # 4. conservation: sum of grad_input == sum of gOut (weights sum to one)
+    assert abs(float(gI.double().sum()) - float(gOut.double().sum())) <= 1e-6 * float(gOut.double().abs().sum())
+    # 5. grad_grid is linear in input: <gG(inp), cG> == <ggOut(cG), gOut> == <gInput_bb(cG), inp>
+    cG = torch.randn_like(grid)
+    bbI, bbG, bbO = ops.backward_backward(None, cG, inp, grid, gOut, off, 0, True, False, 0, True)
+    s1 = float((gG.double() * cG.double()).sum())
+    s2 = float((bbO.double() * gOut.double()).sum())
+    s3 = float((bbI.double() * inp.double()).sum())
+    scale = max(abs(s1), abs(s2), abs(s3), 1.0)
+    assert abs(s1 - s2) <= 2e-6 * scale and abs(s1 - s3) <= 2e-6 * scale
+    # 6. third order: gGrid is linear in input and in gOut: <bbG, hG> == <k4O, gOut> == <k4I, inp>
+    hG = torch.randn_like(grid)
+    k4I, k4O = ops.backward_backward_backward(inp, grid, gOut, cG, hG, off, 0, True, True, 0, True)
+    t1 = float((bbG.double() * hG.double()).sum())
+    t2 = float((k4O.double() * gOut.double()).sum())
+    t3 = float((k4I.double() * inp.double()).sum())
+    scale = max(abs(t1), abs(t2), abs(t3), 1.0)
+    assert abs(t1 - t2) <= 2e-6 * scale and abs(t1 - t3) <= 2e-6 * scale
+    # 7. fused third backward == K4 + the gInput of a K3 run on hO
+    hO = torch.randn_like(gOut)
+    fI, fO = ops.bbb_fused(inp, grid, gOut, cG, hG, hO, off, 0, True, 0, True)
+    extra, _, _ = ops.backward_backward(None, cG, inp, grid, hO, off, 0, True, False, 0, True)
+    assert rel_err(fI, k4I + extra) <= 1e-5
+    assert rel_err(fO, k4O) <= 1e-6
+    # 8. a slice of the full-size result against the CPU oracle (n = 5, first 4096 points)
+    sl = slice(0, 4096)
+    want = cs_oracle.forward(inp[5:6].cpu(), grid[5:6, :, sl].contiguous().cpu(), off[5:6].cpu(), 0, True, 0, True)
+    assert_close(a[5:6, :, :, sl], want, "full-size slice vs oracle")
+
+
+def test_full_size_3d_smoke_properties():
+    # BASELINE.json configs[3]: 3D smoothstep, N=8 C=8 128^3, P=2^19
+    torch.manual_seed(1)
+    N, C, S, P = 8, 8, 128, 1 << 19
+    inp = torch.rand(N, C, S, S, S, device=DEV)
+    grid = (torch.rand(N, 1, 1, P, 3, device=DEV) * 2 - 1)
+    off = multicell_offset(N, True, DEV)
+    out = ops.forward(inp, grid, off, 0, True, 2, True)
+    gOut = torch.randn_like(out)
+    gI, gG = ops.backward(gOut, inp, grid, off, 0, True, True, 2, True)
+    lhs = float((out.double() * gOut.double()).sum())
+    rhs = float((inp.double() * gI.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0)
+    cG = torch.randn_like(grid)
+    bbI, bbG, bbO = ops.backward_backward(None, cG, inp, grid, gOut, off, 0, True, False, 2, True)
+    s1 = float((gG.double() * cG.double()).sum())
+    s2 = float((bbO.double() * gOut.double()).sum())
+    s3 = float((bbI.double() * inp.double()).sum())
+    scale = max(abs(s1), abs(s2), abs(s3), 1.0)
+    assert abs(s1 - s2) <= 2e-6 * scale and abs(s1 - s3) <= 2e-6 * scale
+    sl = slice(0, 2048)
+    want = cs_oracle.forward(inp[3:4].cpu(), grid[3:4, :, :, sl].contiguous().cpu(), off[3:4].cpu(), 0, True, 2, True)
+    assert_close(out[3:4, :, :, :, sl], want, "3D full-size slice vs oracle")
