@@ -48,7 +48,13 @@ def algorithmic_bytes(S, C, d, T):
 def cpu_baseline(N, C, H, seconds_budget=20.0):
     """The PyTorch-autograd CPU path on a bounded sample of the same workload."""
     from oracle import composite
-    cores = os.cpu_count() or 1
+    # the GPU box hands a 1-GPU job a 16-CPU share of a 256-thread host; asking torch for every
+    # hardware thread oversubscribes that share badly (measured: 50x slower)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
 
     def run(P):
