@@ -135,18 +135,22 @@ def main():
 
     def step(record):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        # A fresh StepContext every step: the channels-last copy of `cells` and the point plan of
+        # `grid` are rebuilt inside the timed region each step (forward pays the copy, backward the
+        # plan), exactly as one CosineSampler2d.apply + its backward chain would.
+        sc = ops.StepContext()
         if record:
             e[0].record()
-        out = ops.forward(cells, grid, off, pad, align, kern, mc)
+        out = ops.forward(cells, grid, off, pad, align, kern, mc, ctx=sc)
         if record:
             e[1].record()
-        gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc)
+        gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc, ctx=sc)
         if record:
             e[2].record()
-        bbI, bbG, bbO = ops.backward_backward(None, cG, cells, grid, gOut, off, pad, align, False, kern, mc)
+        bbI, bbG, bbO = ops.backward_backward(None, cG, cells, grid, gOut, off, pad, align, False, kern, mc, ctx=sc)
         if record:
             e[3].record()
-        tI, tO = ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, pad, align, kern, mc)
+        tI, tO = ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, pad, align, kern, mc, ctx=sc)
         if record:
             e[4].record()
             ev.append(e)

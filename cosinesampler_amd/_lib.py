@@ -20,10 +20,12 @@ _STAGES = {
     "backward_backward_backward": 8,
     "bbb_fused": 9,
 }
-EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes"]
+EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_pack_bytes", "cs_pack_input",
+            "cs2d_plan_bytes", "cs2d_plan_build", "cs_debug_force_path"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES])
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 
 
@@ -45,7 +47,17 @@ def load():
     lib.cs_error_string.restype = ctypes.c_char_p
     lib.cs_error_string.argtypes = [_c_int]
     lib.cs_workspace_bytes.restype = _c_sz
-    lib.cs_workspace_bytes.argtypes = [_c_int, _c_int] + [_c_i64] * 6
+    lib.cs_workspace_bytes.argtypes = [_c_int, _c_int] + [_c_i64] * 6 + [_c_int] * 3
+    lib.cs_pack_bytes.restype = _c_sz
+    lib.cs_pack_bytes.argtypes = [_c_int] + [_c_i64] * 6
+    lib.cs_pack_input.restype = _c_int
+    lib.cs_pack_input.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 5 + [_c_f]
+    lib.cs2d_plan_bytes.restype = _c_sz
+    lib.cs2d_plan_bytes.argtypes = [_c_i64] * 5
+    lib.cs2d_plan_build.restype = _c_int
+    lib.cs2d_plan_build.argtypes = [_c_f, _c_f, _c_f, _c_sz] + [_c_i64] * 5 + [_c_int] * 3 + [_c_f]
+    lib.cs_debug_force_path.restype = None
+    lib.cs_debug_force_path.argtypes = [_c_int]
     if lib.cs_abi_version() != ABI_VERSION:
         raise RuntimeError("cosinesampler_amd: %s has ABI %d, host code wants %d -- rebuild"
                            % (path, lib.cs_abi_version(), ABI_VERSION))
@@ -53,7 +65,7 @@ def load():
         for stage, nptr in _STAGES.items():
             fn = getattr(lib, "cs%dd_%s" % (dim, stage))
             fn.restype = _c_int
-            fn.argtypes = [_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + [_c_f, _c_sz, _c_f]
+            fn.argtypes = [_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + [_c_f, _c_f, _c_f, _c_sz, _c_f]
     _lib = lib
     return lib
 

@@ -1,17 +1,22 @@
 // cs_abi.hip -- extern "C" entry points of libcosine_sampler_hip.so (see include/cosine_sampler.h).
-// Host side only: argument checks, stage -> kernel dispatch, launches on the caller's stream.
+// Host side only: argument checks, path choice, workspace carving, launches on the caller's stream.
 // Nothing here allocates, frees, copies to the host or synchronises.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/cosine_sampler.h"
 #include "cs_kernels_direct.cuh"
+#include "cs_tiled.cuh"
 
 namespace {
 
 using cs::Dims;
 using cs::Flags;
+namespace tl = cs::tiled;
 
 constexpr int kBlock = 256;
+std::atomic<int> g_force_path{0};  // cs_debug_force_path
 
 struct Problem {
     Dims d;
@@ -67,6 +72,9 @@ int zero_async(float *p, int64_t elems, hipStream_t s) {
         default:               { constexpr int KERNEL = cs::K_SMOOTHSTEP; __VA_ARGS__; } break;   \
     }
 
+// ------------------------------------------------------------------------------------------------
+// direct path (any shape)
+// ------------------------------------------------------------------------------------------------
 template <int DIM>
 int run_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output) {
     if (pb.d.S == 0 || pb.d.C == 0) return CS_OK;
@@ -110,6 +118,251 @@ int run_bbb(const Problem &pb, const float *input, const float *grid, const floa
     return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// tiled path (2D, C in {4,8,16})
+// ------------------------------------------------------------------------------------------------
+constexpr int64_t kTiledMinSamples = 1 << 16;  // below this the launch count matters more than atomics
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
+    int mode = g_force_path.load(std::memory_order_relaxed);
+    if (mode == 1 || dim != 2) return false;
+    if (!(C == 4 || C == 8 || C == 16)) return false;
+    int64_t S = N * P;
+    if (S <= 0 || S >= (int64_t)0xFFFFFFF0ll) return false;
+    int64_t ntx = (W + 1 + tl::TX - 1) / tl::TX, nty = (H + 1 + tl::TY - 1) / tl::TY;
+    if (ntx * nty > 12288) return false;                 // tile histogram lives in LDS (48 KiB)
+    if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
+    if (mode == 2) return true;
+    return S >= kTiledMinSamples;
+}
+
+struct PlanLayout {
+    int ntx, nty, ntiles, chunks;
+    size_t off_rank1, off_cell1, off_ord, off_ocell, off_tile_begin, off_block_hist, off_totals, bytes;
+};
+
+PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
+    PlanLayout L;
+    L.ntx = (int)((W + 1 + tl::TX - 1) / tl::TX);
+    L.nty = (int)((H + 1 + tl::TY - 1) / tl::TY);
+    L.ntiles = L.ntx * L.nty;
+    L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
+    int64_t S = N * P;
+    size_t o = 0;
+    L.off_rank1 = o;      o += align256((size_t)S * 4);
+    L.off_cell1 = o;      o += align256((size_t)S);
+    L.off_ord = o;        o += align256((size_t)S * 4);
+    L.off_ocell = o;      o += align256((size_t)S);
+    L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
+    L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
+    L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
+    L.bytes = o;
+    return L;
+}
+
+tl::Plan plan_view(const PlanLayout &L, void *blob) {
+    char *b = (char *)blob;
+    tl::Plan p;
+    p.rank1 = (uint32_t *)(b + L.off_rank1);
+    p.cell1 = (uint8_t *)(b + L.off_cell1);
+    p.ord = (uint32_t *)(b + L.off_ord);
+    p.ocell = (uint8_t *)(b + L.off_ocell);
+    p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
+    p.block_hist = (uint32_t *)(b + L.off_block_hist);
+    p.ntx = L.ntx;
+    p.nty = L.nty;
+    p.ntiles = L.ntiles;
+    p.chunks = L.chunks;
+    return p;
+}
+
+int build_plan(const Problem &pb, const float *grid, const float *offset, void *blob) {
+    PlanLayout L = plan_layout(pb.d.N, pb.d.size[1], pb.d.size[0], pb.d.P);
+    tl::Plan pl = plan_view(L, blob);
+    uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
+    dim3 g((unsigned)L.chunks, (unsigned)pb.d.N);
+    size_t shm = (size_t)L.ntiles * 4;
+    tl::plan_count<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    int64_t nt = (int64_t)pb.d.N * L.ntiles;
+    tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
+    tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
+    tl::plan_scatter<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl);
+    return launch_status();
+}
+
+int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipStream_t s) {
+    if (N == 0 || C == 0 || vol == 0) return CS_OK;
+    dim3 g((unsigned)((vol + 63) / 64), (unsigned)N);
+    tl::pack_channels_last<<<g, 256, (size_t)C * 65 * 4, s>>>(in, out, (int)C, vol);
+    return launch_status();
+}
+
+// carve the workspace: [input_cl?][plan?][cI_cl?][rows1][coef1][rows2][coef2]
+struct Carve {
+    char *base;
+    size_t used, cap;
+    void *take(size_t bytes) {
+        void *p = base + used;
+        used += align256(bytes);
+        return p;
+    }
+    bool ok() const { return used <= cap; }
+};
+
+size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
+                       int have_cI) {
+    size_t T = align256((size_t)N * C * H * W * 4);
+    size_t S = (size_t)N * P;
+    size_t need = 0;
+    if (!have_cl) need += T;
+    if (stage == CS_STAGE_FORWARD) return need;
+    if (!have_plan) need += plan_layout(N, H, W, P).bytes;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    size_t rows = align256(S * C * 4), coef = align256(S * 16);
+    need += rows + coef;
+    if (stage == CS_STAGE_BBB_FUSED) need += rows + coef;
+    return need;
+}
+
+template <bool TWO>
+int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *rows1, const float4 *coef1,
+                        const float *rows2, const float4 *coef2, float *grad_input) {
+    unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntiles);
+    switch (pb.d.C) {
+        case 4: tl::tile_scatter<2, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
+        case 8: tl::tile_scatter<3, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
+        default: tl::tile_scatter<4, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
+    }
+    return launch_status();
+}
+
+struct Prepared {
+    const float *icl;
+    tl::Plan plan;
+};
+
+// resolve input_cl / plan: use the caller's, or build into the workspace
+int prepare(const Problem &pb, int stage, const float *input, const float *grid, const float *offset,
+            const float *input_cl, const void *plan, Carve &ws, Prepared &out) {
+    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
+    if (input_cl) {
+        out.icl = input_cl;
+    } else {
+        float *buf = (float *)ws.take((size_t)T * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        if (rc) return rc;
+        out.icl = buf;
+    }
+    if (stage == CS_STAGE_FORWARD) return CS_OK;
+    PlanLayout L = plan_layout(pb.d.N, pb.d.size[1], pb.d.size[0], pb.d.P);
+    if (plan) {
+        out.plan = plan_view(L, const_cast<void *>(plan));
+    } else {
+        void *blob = ws.take(L.bytes);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = build_plan(pb, grid, offset, blob);
+        if (rc) return rc;
+        out.plan = plan_view(L, blob);
+    }
+    return CS_OK;
+}
+
+size_t point_lds(int C, int nrows) { return (size_t)4 * (64 + 64 * nrows * C) * 4; }
+
+int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
+                  const float *input_cl, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared pr;
+    int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_forward<KERNEL><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      pr.icl, grid, offset, output, pb.d, pb.f)));
+    return launch_status();
+}
+
+int tiled_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
+                   float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
+                   size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared pr;
+    // without grad_input nothing is scattered: no plan, no rows
+    int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    float *rows = nullptr;
+    float4 *coef = nullptr;
+    if (grad_input) {
+        rows = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
+        coef = (float4 *)ws.take((size_t)pb.d.S * 16);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+    }
+    const uint32_t *rank1 = grad_input ? pr.plan.rank1 : nullptr;
+    size_t shm = point_lds(pb.d.C, 1);
+    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_backward<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                      gOut, pr.icl, grid, offset, rank1, rows, coef, grad_grid, pb.d, pb.f)));
+    rc = launch_status();
+    if (rc || !grad_input) return rc;
+    return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, grad_input);
+}
+
+int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
+             const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut,
+             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared pr;
+    int rc = prepare(pb, CS_STAGE_BACKWARD_BACKWARD, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    const float *cIcl = nullptr;
+    if (cI) {
+        float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        if (rc) return rc;
+        cIcl = buf;
+    }
+    float *rows = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
+    float4 *coef = (float4 *)ws.take((size_t)pb.d.S * 16);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    if (rc) return rc;
+    size_t shm = point_lds(pb.d.C, 1);
+    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_bb<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                      cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank1, rows, coef, gGrid, ggOut,
+                                      pb.d, pb.f)));
+    rc = launch_status();
+    if (rc) return rc;
+    return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, gInput);
+}
+
+int tiled_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
+              const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
+              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared pr;
+    int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    float *rows1 = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
+    float4 *coef1 = (float4 *)ws.take((size_t)pb.d.S * 16);
+    float *rows2 = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
+    float4 *coef2 = (float4 *)ws.take((size_t)pb.d.S * 16);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    if (rc) return rc;
+    size_t shm = point_lds(pb.d.C, 2);
+    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_bbb<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                      pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank1, rows1, coef1, rows2,
+                                      coef2, ggOut, pb.d, pb.f)));
+    rc = launch_status();
+    if (rc) return rc;
+    if (hO) return launch_tile_scatter<true>(pb, pr.plan, rows1, coef1, rows2, coef2, gInput);
+    return launch_tile_scatter<false>(pb, pr.plan, rows1, coef1, nullptr, nullptr, gInput);
+}
+
 bool any_null(std::initializer_list<const void *> ps) {
     for (const void *p : ps)
         if (!p) return true;
@@ -132,18 +385,57 @@ const char *cs_error_string(int code) {
     }
 }
 
-size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
-    (void)dim; (void)stage; (void)N; (void)C; (void)D; (void)H; (void)W; (void)P;
-    return 0;  // the direct kernels need no scratch
+void cs_debug_force_path(int mode) { g_force_path.store(mode, std::memory_order_relaxed); }
+
+size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                          int have_input_cl, int have_plan, int have_cI) {
+    (void)D;
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
+    if (!tiled_applies(dim, N, C, H, W, P)) return 0;
+    return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
+}
+
+size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+    if (!tiled_applies(dim, N, C, H, W, P)) return 0;
+    return align256((size_t)N * C * D * H * W * 4);
+}
+
+int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
+                  int64_t W, void *stream) {
+    if (dim != 2 && dim != 3) return CS_ERR_INVALID;
+    if (N < 0 || C < 0 || D < 1 || H < 1 || W < 1 || (C & 3)) return CS_ERR_INVALID;
+    if (N * C > 0 && (!input || !input_cl)) return CS_ERR_INVALID;
+    if (C * 65 * 4 > 64 * 1024) return CS_ERR_UNSUPPORTED;
+    return pack_cl(input, input_cl, N, C, (dim == 3 ? D : 1) * H * W, (hipStream_t)stream);
+}
+
+size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
+    if (!tiled_applies(2, N, C, H, W, P)) return 0;
+    return plan_layout(N, H, W, P).bytes;
+}
+
+int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
+                    int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int multicell,
+                    void *stream) {
+    Problem pb;
+    int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, 0, multicell, stream);
+    if (rc) return rc;
+    if (!tiled_applies(2, N, C, H, W, P)) return CS_ERR_UNSUPPORTED;
+    if (!grid || !offset || !plan) return CS_ERR_INVALID;
+    if (plan_bytes < plan_layout(N, H, W, P).bytes) return CS_ERR_WORKSPACE;
+    return build_plan(pb, grid, offset, plan);
 }
 
 #define CS_PROBLEM(dim, D)                                                                                        \
     Problem pb;                                                                                                   \
-    (void)workspace; (void)workspace_bytes;                                                                       \
     {                                                                                                             \
         int rc_ = make_problem(pb, dim, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream); \
         if (rc_) return rc_;                                                                                      \
-    }
+    }                                                                                                             \
+    const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
+    (void)tiled; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;
 
 // zero-element tensors legitimately come with null data pointers
 #define CS_NEED(...)                                                            \
@@ -152,18 +444,22 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
 // ---- 2D ----
 int cs2d_forward(const float *input, const float *grid, const float *offset, float *output, int64_t N, int64_t C,
                  int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int kernel, int multicell,
-                 void *workspace, size_t workspace_bytes, void *stream) {
+                 const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, offset, output)
+    if (tiled) return tiled_forward(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     return run_forward<2>(pb, input, grid, offset, output);
 }
 
 int cs2d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input, float *grad_grid, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                  int padding_mode, int align_corners, int kernel, int multicell, void *workspace,
-                  size_t workspace_bytes, void *stream) {
+                  int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                  const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    if (tiled)
+        return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
+                              workspace_bytes);
     return run_backward<2>(pb, grad_output, input, grid, offset, grad_input, grad_grid);
 }
 
@@ -171,9 +467,13 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            const float *grid, const float *grad_output, const float *offset, float *grad_input,
                            float *grad_grid, float *grad_grad_out, int64_t N, int64_t C, int64_t H, int64_t W,
                            int64_t P, int padding_mode, int align_corners, int kernel, int multicell,
-                           void *workspace, size_t workspace_bytes, void *stream) {
+                           const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
+                           void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
+    if (tiled)
+        return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
+                        grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     return run_bb<2>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                      grad_grad_out);
 }
@@ -182,9 +482,13 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out, int64_t N, int64_t C, int64_t H,
                                     int64_t W, int64_t P, int padding_mode, int align_corners, int kernel,
-                                    int multicell, void *workspace, size_t workspace_bytes, void *stream) {
+                                    int multicell, const float *input_cl, const void *plan, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    if (tiled)
+        return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
+                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     return run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                       grad_grad_out);
 }
@@ -192,18 +496,22 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
 int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
                    const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_input,
                    float *grad_grad_out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode,
-                   int align_corners, int kernel, int multicell, void *workspace, size_t workspace_bytes,
-                   void *stream) {
+                   int align_corners, int kernel, int multicell, const float *input_cl, const void *plan,
+                   void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    if (tiled)
+        return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                         grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     return run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                       grad_input, grad_grad_out);
 }
 
-// ---- 3D ----
+// ---- 3D (direct path only for now) ----
 int cs3d_forward(const float *input, const float *grid, const float *offset, float *output, int64_t N, int64_t C,
                  int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int kernel,
-                 int multicell, void *workspace, size_t workspace_bytes, void *stream) {
+                 int multicell, const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
+                 void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, offset, output)
     return run_forward<3>(pb, input, grid, offset, output);
@@ -211,8 +519,8 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
 
 int cs3d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input, float *grad_grid, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W,
-                  int64_t P, int padding_mode, int align_corners, int kernel, int multicell, void *workspace,
-                  size_t workspace_bytes, void *stream) {
+                  int64_t P, int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                  const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(grad_output, input, grid, offset, grad_grid)
     return run_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid);
@@ -222,7 +530,8 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            const float *grid, const float *grad_output, const float *offset, float *grad_input,
                            float *grad_grid, float *grad_grad_out, int64_t N, int64_t C, int64_t D, int64_t H,
                            int64_t W, int64_t P, int padding_mode, int align_corners, int kernel, int multicell,
-                           void *workspace, size_t workspace_bytes, void *stream) {
+                           const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
+                           void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
     return run_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
@@ -233,8 +542,8 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out, int64_t N, int64_t C, int64_t D,
                                     int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners,
-                                    int kernel, int multicell, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
+                                    int kernel, int multicell, const float *input_cl, const void *plan,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
     return run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
@@ -244,8 +553,8 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
 int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
                    const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_input,
                    float *grad_grad_out, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                   int padding_mode, int align_corners, int kernel, int multicell, void *workspace,
-                   size_t workspace_bytes, void *stream) {
+                   int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                   const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
     return run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,

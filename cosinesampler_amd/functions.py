@@ -86,10 +86,12 @@ def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multice
         raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
     cfg = _Config(padding_mode, align_corners, kernel, multicell)
     offset = multicell_offset(input.shape[0], multicell, input.device)
-    output = ops.forward(input, grid, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell)
+    step = ops.StepContext()   # channels-last input copy + point plan, shared by this call's backward chain
+    output = ops.forward(input, grid, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step)
     ctx.save_for_backward(input, grid)
     ctx.offset = offset
     ctx.cfg = cfg
+    ctx.step = step
     return output
 
 
@@ -98,7 +100,7 @@ def _backward(ctx, grad_out):
     if grad_out is None:
         return None, None, None, None, None, None
     d_input, d_grid = _SamplerBackward.apply(input, grid, _c(grad_out), ctx.offset, ctx.cfg,
-                                             ctx.needs_input_grad[0])
+                                             ctx.needs_input_grad[0], ctx.step)
     return d_input, d_grid, None, None, None, None
 
 
@@ -129,12 +131,13 @@ class _SamplerBackward(Function):
     modules_2d.py:47-74."""
 
     @staticmethod
-    def forward(ctx, input, grid, gOut, offset, cfg, input_requires_grad):
+    def forward(ctx, input, grid, gOut, offset, cfg, input_requires_grad, step):
         ctx.set_materialize_grads(False)
         ctx.offset = offset
         ctx.cfg = cfg
+        ctx.step = step
         grad_input, grad_grid = ops.backward(gOut, input, grid, offset, cfg.pad, cfg.align_corners,
-                                             bool(input_requires_grad), cfg.kernel, cfg.multicell)
+                                             bool(input_requires_grad), cfg.kernel, cfg.multicell, ctx=step)
         ctx.save_for_backward(input, grid, gOut)
         return grad_input, grad_grid
 
@@ -142,10 +145,10 @@ class _SamplerBackward(Function):
     def backward(ctx, gOutInput, gOutGrid):
         input, grid, gOut = ctx.saved_tensors
         if gOutInput is None and gOutGrid is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
-                                                              ctx.offset, ctx.cfg)
-        return gInput, gGrid, ggOut, None, None, None
+                                                              ctx.offset, ctx.cfg, ctx.step)
+        return gInput, gGrid, ggOut, None, None, None, None
 
 
 class _SamplerBackwardBackward(Function):
@@ -153,13 +156,14 @@ class _SamplerBackwardBackward(Function):
     CosineSamplerBackwardBackward, modules_2d.py:76-111."""
 
     @staticmethod
-    def forward(ctx, input, grid, gOut, gOutInput, gOutGrid, offset, cfg):
+    def forward(ctx, input, grid, gOut, gOutInput, gOutGrid, offset, cfg, step):
         ctx.set_materialize_grads(False)
         ctx.offset = offset
         ctx.cfg = cfg
+        ctx.step = step
         gInput, gGrid, ggOut = ops.backward_backward(gOutInput, gOutGrid, input, grid, gOut, offset, cfg.pad,
                                                      cfg.align_corners, gOutInput is not None, cfg.kernel,
-                                                     cfg.multicell)
+                                                     cfg.multicell, ctx=step)
         ctx.has_cG = gOutGrid is not None
         if gOutGrid is None:
             ctx.save_for_backward(input, grid, gOut)
@@ -176,8 +180,8 @@ class _SamplerBackwardBackward(Function):
         else:
             (input, grid, gOut), gOutGrid = ctx.saved_tensors, None
         if gOutgGrid is None and gOutggOut is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         cfg = ctx.cfg
         gInput, ggOut = ops.bbb_fused(input, grid, gOut, gOutGrid, _c(gOutgGrid), _c(gOutggOut), ctx.offset,
-                                      cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell)
-        return gInput, None, ggOut, None, None, None, None
+                                      cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
+        return gInput, None, ggOut, None, None, None, None, None

@@ -64,33 +64,97 @@ def _offset_ok(offset, N, device):
         raise RuntimeError("offset must hold N=%d floats on %s" % (N, device))
 
 
-def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device):
+class StepContext(object):
+    """Prepared objects that the stages of ONE training step share (include/cosine_sampler.h,
+    `input_cl` / `plan`): the channels-last copy of `input` and the point-binning plan of `grid`.
+    Built lazily on first use, keyed on the tensors' storage address, version counter and shape,
+    and dropped with the context.  The autograd Functions create one per forward call, so nothing
+    outlives the graph it belongs to; pass `ctx=None` to let every stage work from scratch."""
+
+    def __init__(self):
+        self._cl = None
+        self._cl_key = None
+        self._plan = None
+        self._plan_key = None
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), t.device)
+
+    def input_cl(self, lib, input, dim, shape, P, stream):
+        key = self._key(input)
+        if self._cl_key != key:
+            D = shape[2] if dim == 3 else 1
+            nbytes = lib.cs_pack_bytes(dim, shape[0], shape[1], D, shape[-2], shape[-1], P)
+            self._cl, self._cl_key = None, key
+            if nbytes:
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
+                _lib.check(lib.cs_pack_input(dim, input.data_ptr(), buf.data_ptr(), shape[0], shape[1], D, shape[-2],
+                                             shape[-1], stream), "cs_pack_input")
+                self._cl = buf
+        return self._cl
+
+    def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
+        if dim != 2:
+            return None
+        key = self._key(grid) + (offset.data_ptr(), shape[2], shape[3], int(padding_mode), bool(align_corners),
+                                 bool(multicell))
+        if self._plan_key != key:
+            nbytes = lib.cs2d_plan_bytes(shape[0], shape[1], shape[2], shape[3], P)
+            self._plan, self._plan_key = None, key
+            if nbytes:
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
+                _lib.check(lib.cs2d_plan_build(grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, shape[0],
+                                               shape[1], shape[2], shape[3], P, int(padding_mode),
+                                               int(bool(align_corners)), int(bool(multicell)), stream),
+                           "cs2d_plan_build")
+                self._plan = buf
+        return self._plan
+
+
+def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
+          grid=None, offset=None, want_plan=False, have_cI=False):
     if kernel not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), got %r" % (kernel,))
     lib = _lib.load()
     fn = getattr(lib, "cs%dd_%s" % (dim, stage))
+    D = shape[2] if dim == 3 else 1
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
+        cl = plan = None
+        if ctx is not None:
+            cl = ctx.input_cl(lib, input, dim, shape, P, stream)
+            if want_plan:
+                plan = ctx.plan(lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream)
+        need = lib.cs_workspace_bytes(dim, _lib.STAGE_ID[stage], shape[0], shape[1], D, shape[-2], shape[-1], P,
+                                      int(cl is not None), int(plan is not None), int(have_cI))
+        ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
-                None, 0, stream)
+                _ptr(cl), _ptr(plan), _ptr(ws), need, stream)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
+
+
+def force_path(mode):
+    """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 tiled path wherever it exists."""
+    _lib.load().cs_debug_force_path(int(mode))
 
 
 def out_shape(input, grid):
     return tuple(input.shape[:2]) + tuple(grid.shape[1:-1])
 
 
-def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell):
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     output = torch.empty(out_shape(input, grid), dtype=input.dtype, device=input.device)
     _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P,
-          padding_mode, align_corners, kernel, multicell, input.device)
+          padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset)
     return output
 
 
-def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell):
+def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
+             ctx=None):
     """-> (grad_input | None, grad_grid); grad_input is None when input_requires_grad is False
     (the reference returns an undefined Tensor, 2d.cpp:73-79)."""
     dim, shape, P = _problem(input, grid)
@@ -99,12 +163,13 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     grad_input = torch.empty_like(input) if input_requires_grad else None
     grad_grid = torch.empty_like(grid)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
-                            _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+                            _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
+          ctx, input, grid, offset, want_plan=bool(input_requires_grad))
     return grad_input, grad_grid
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell):
+                      input_requires_grad, kernel, multicell, ctx=None):
     """-> (grad_input, grad_grid, grad_grad_out).  grad_out_input is only read when
     input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros)."""
     dim, shape, P = _problem(input, grid)
@@ -122,12 +187,13 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
     _call("backward_backward", dim,
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_plan=True, have_cI=grad_out_input is not None)
     return grad_input, grad_grid, grad_grad_out
 
 
 def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, padding_mode,
-                               align_corners, input_requires_grad, kernel, multicell):
+                               align_corners, input_requires_grad, kernel, multicell, ctx=None):
     """-> (grad_input, grad_grad_out).  `input_requires_grad` is accepted and ignored, as in the
     reference kernel (2d.cu:736)."""
     dim, shape, P = _problem(input, grid)
@@ -140,12 +206,13 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
     _call("backward_backward_backward", dim,
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_plan=True)
     return grad_input, grad_grad_out
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
-              align_corners, kernel, multicell):
+              align_corners, kernel, multicell, ctx=None):
     """-> (grad_input, grad_grad_out) of the whole third backward (reference modules_2d.py:98-111):
     grad_input = K4.gInput + K3(gOut := grad_out_ggout, gOutInput := ones).gInput in one pass.
     grad_out_grid / grad_out_ggrid / grad_out_ggout may each be None (= zeros)."""
@@ -162,5 +229,6 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
     _call("bbb_fused", dim,
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device)
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_plan=True)
     return grad_input, grad_grad_out

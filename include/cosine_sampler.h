@@ -25,6 +25,13 @@
  *   - `workspace`: scratch device memory, at least cs_workspace_bytes(...) bytes, 256-byte
  *     aligned, owned by the caller, contents undefined before and after.  May be NULL when the
  *     query returns 0.
+ *   - `input_cl`, `plan` (both nullable): prepared objects that let consecutive stages of one
+ *     training step share work.  `input_cl` is the channels-last copy of `input` made by
+ *     cs_pack_input(); `plan` is the point-binning plan made by cs2d_plan_build() for THIS grid,
+ *     offset, sizes and flags.  The library cannot check that they match (they live in device
+ *     memory and nothing here synchronises): passing a stale one is undefined behaviour.  When
+ *     NULL, a stage that wants them builds them inside `workspace` (cs_workspace_bytes accounts
+ *     for it).  Problems outside the fast path (3D, C not in {4,8,16}, tiny S) ignore both.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
  *   - Thread-safe and re-entrant: the library keeps no mutable global state.
@@ -39,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -50,8 +57,29 @@ enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD =
 int cs_abi_version(void);
 const char *cs_error_string(int code);
 
-/* Scratch bytes stage `stage` needs for this problem.  dim = 2 or 3; D is ignored for dim 2. */
-size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
+/* Scratch bytes stage `stage` needs for this problem.  dim = 2 or 3; D is ignored for dim 2.
+ * have_input_cl / have_plan: the caller will pass those prepared objects; have_cI: the
+ * backward_backward call will carry a grad_out_input (it needs its own channels-last copy). */
+size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                          int have_input_cl, int have_plan, int have_cI);
+
+/* Channels-last copy (N,spatial...,C) of an (N,C,spatial...) tensor; C % 4 == 0.  Returns the
+ * byte size of the copy / makes it.  cs_pack_bytes returns 0 when the fast path does not apply. */
+size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
+int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
+                  int64_t W, void *stream);
+
+/* Point-binning plan of one grid (2D fast path): tile-sorted slot of every sample + the cell-sorted
+ * visiting order inside every 16x16-cell tile.  Depends on grid, offset, N, H, W, P and the three
+ * flags, not on C or the blending kernel.  cs2d_plan_bytes returns 0 when the fast path does not apply. */
+size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P);
+int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
+                    int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                    int padding_mode, int align_corners, int multicell, void *stream);
+
+/* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
+ * kernels, 2 = the tiled path wherever it is implemented, whatever the size.  Process-wide. */
+void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */
 
@@ -60,7 +88,7 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
 int cs2d_forward(const float *input, const float *grid, const float *offset, float *output,
                  int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                  int padding_mode, int align_corners, int kernel, int multicell,
-                 void *workspace, size_t workspace_bytes, void *stream);
+                 const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces `_cosine_2d.backward` (2d.cpp:64-85 -> 2d.cu:938).
  * grad_input == NULL  <=>  input_requires_grad == false (2d.cpp:73-79). */
@@ -68,7 +96,7 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
                   float *grad_input /* nullable */, float *grad_grid,
                   int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                   int padding_mode, int align_corners, int kernel, int multicell,
-                  void *workspace, size_t workspace_bytes, void *stream);
+                  const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces `_cosine_2d.backward_backward` (2d.cpp:87-106 -> 2d.cu:990).
  * grad_out_input == NULL <=> input_requires_grad == false (modules_2d.py:87-89).
@@ -78,7 +106,7 @@ int cs2d_backward_backward(const float *grad_out_input /* nullable */, const flo
                            float *grad_input, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                            int padding_mode, int align_corners, int kernel, int multicell,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces `_cosine_2d.backward_backward_backward` (2d.cpp:108-127 -> 2d.cu:1058). */
 int cs2d_backward_backward_backward(const float *input, const float *grid, const float *grad_output,
@@ -86,7 +114,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
                                     float *grad_input, float *grad_grad_out,
                                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                                     int padding_mode, int align_corners, int kernel, int multicell,
-                                    void *workspace, size_t workspace_bytes, void *stream);
+                                    const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The whole of CosineSamplerBackwardBackward.backward (modules_2d.py:98-111) in one pass: the
  * kernel above PLUS the reference's second backward_backward launch with gOut := grad_out_ggout,
@@ -100,34 +128,34 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    float *grad_input, float *grad_grad_out,
                    int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                    int padding_mode, int align_corners, int kernel, int multicell,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- 3D: same contracts; 3d.cpp:50-131 -> 3d.cu:1073,1115,1167,1241; modules_3d.py:87-100 --- */
 
 int cs3d_forward(const float *input, const float *grid, const float *offset, float *output,
                  int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                  int padding_mode, int align_corners, int kernel, int multicell,
-                 void *workspace, size_t workspace_bytes, void *stream);
+                 const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input /* nullable */, float *grad_grid,
                   int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                   int padding_mode, int align_corners, int kernel, int multicell,
-                  void *workspace, size_t workspace_bytes, void *stream);
+                  const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
                            const float *input, const float *grid, const float *grad_output, const float *offset,
                            float *grad_input, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                            int padding_mode, int align_corners, int kernel, int multicell,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_backward_backward_backward(const float *input, const float *grid, const float *grad_output,
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out,
                                     int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                                     int padding_mode, int align_corners, int kernel, int multicell,
-                                    void *workspace, size_t workspace_bytes, void *stream);
+                                    const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_output,
                    const float *grad_out_grid, const float *grad_out_ggrid /* nullable */,
@@ -135,7 +163,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    float *grad_input, float *grad_grad_out,
                    int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                    int padding_mode, int align_corners, int kernel, int multicell,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

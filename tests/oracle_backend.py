@@ -10,19 +10,20 @@ def _f(t):
     return None if t is None else t.contiguous()
 
 
-def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell):
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
     if kernel not in (0, 1, 2):
         raise TypeError("kernel enum")
     return cs_oracle.forward(_f(input), _f(grid), offset, padding_mode, align_corners, kernel, multicell)
 
 
-def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell):
+def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
+             ctx=None):
     return cs_oracle.backward(_f(grad_output), _f(input), _f(grid), offset, padding_mode, align_corners,
                               input_requires_grad, kernel, multicell)
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell):
+                      input_requires_grad, kernel, multicell, ctx=None):
     if grad_out_grid is None:
         grad_out_grid = torch.zeros_like(grid)
     return cs_oracle.backward_backward(_f(grad_out_input), _f(grad_out_grid), _f(input), _f(grid), _f(grad_output),
@@ -30,7 +31,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
-              align_corners, kernel, multicell):
+              align_corners, kernel, multicell, ctx=None):
     z = torch.zeros_like(grid)
     return cs_oracle.bbb_fused(_f(input), _f(grid), _f(grad_output),
                                z if grad_out_grid is None else _f(grad_out_grid),

@@ -37,9 +37,20 @@ def test_loader_binds_and_reports_errors_without_gpu():
     lib = _lib.load()
     assert lib.cs_error_string(0) == b"ok"
     assert b"invalid" in lib.cs_error_string(-1)
-    assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20) >= 0
+    # headline config: the tiled path wants scratch for the channels-last copy (64 MiB) in forward ...
+    assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 16 * 256 * 256 * 4
+    assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
+    # ... payload rows + coefficient records in backward (plus the plan unless one is passed in)
+    S = 16 << 20
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 64 + S * 16
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == (
+        S * 80 + lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20))
+    # shapes outside the fast path (3D, odd channel counts, tiny sample counts) need none
+    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == 0
+    assert lib.cs_workspace_bytes(2, 1, 16, 3, 1, 256, 256, 1 << 20, 0, 0, 0) == 0
+    assert lib.cs_workspace_bytes(2, 1, 1, 16, 1, 32, 32, 1024, 0, 0, 0) == 0
     # argument validation happens before any device work: callable without a GPU
-    rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, 0, None)
+    rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, None, None, 0, None)
     assert rc == -1  # padding_mode 7 is not a mode
 
 

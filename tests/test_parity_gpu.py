@@ -86,6 +86,65 @@ def test_every_stage_matches_cpu_oracle(d, ke, mc, pad, align):
         assert_close(got[k], want[k], "d=%d kernel=%d mc=%s pad=%d align=%s: %s" % (d, ke, mc, pad, align, k))
 
 
+TILED_CASES = []
+for _C in (4, 8, 16):
+    for _ke in (0, 1, 2):
+        for _pad, _align, _mc in ((0, True, True), (0, False, False), (1, True, False), (2, True, True),
+                                  (2, False, False)):
+            TILED_CASES.append((_C, _ke, _pad, _align, _mc))
+
+
+@pytest.mark.parametrize("C,ke,pad,align,mc", TILED_CASES)
+@pytest.mark.parametrize("shared", [False, True])
+def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
+    """The fast 2D path (channels-last gathers + plan + payload rows + tile walkers), forced on
+    for a small problem that still spans several tiles, ragged edges and out-of-range points."""
+    N, P, sp = 3, 3001, (37, 50)
+    t = _case(2, N, C, sp, P, seed=7000 + C + 10 * ke + pad, spread=1.15)
+    off = offsets(N, mc)
+    want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
+    ops.force_path(2)
+    try:
+        if shared:      # one StepContext across the stages, as the autograd chain uses it
+            step = ops.StepContext()
+
+            class Shared(object):
+                def __getattr__(self, name):
+                    fn = getattr(ops, name)
+                    return lambda *a: fn(*a, ctx=step)
+            got = _run_all_stages(Shared(), t, off, pad, align, ke, mc, DEV)
+        else:
+            got = _run_all_stages(ops, t, off, pad, align, ke, mc, DEV)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for k in want:
+        assert_close(got[k], want[k], "tiled C=%d kernel=%d pad=%d align=%s mc=%s shared=%s: %s"
+                     % (C, ke, pad, align, mc, shared, k))
+
+
+def test_tiled_path_empty_and_clustered_points():
+    """Degenerate point sets for the plan: every point in one cell, every point out of range."""
+    N, C, sp = 2, 16, (40, 33)
+    off = offsets(N, True)
+    ops.force_path(2)
+    try:
+        for kind in ("one_cell", "all_outside", "two_points"):
+            P = 2 if kind == "two_points" else 5000
+            t = _case(2, N, C, sp, P, seed=99)
+            if kind == "one_cell":
+                t["grid"] = (torch.rand_like(t["grid"]) * 0.01 + 0.3)
+            elif kind == "all_outside":
+                t["grid"] = torch.rand_like(t["grid"]) + 3.0
+            want = _run_all_stages(cs_oracle, t, off, 0, True, 0, True, "cpu")
+            got = _run_all_stages(ops, t, off, 0, True, 0, True, DEV)
+            torch.cuda.synchronize()
+            for k in want:
+                assert_close(got[k], want[k], "tiled %s: %s" % (kind, k))
+    finally:
+        ops.force_path(0)
+
+
 @pytest.mark.parametrize("name", stage_fixtures())
 def test_stage_golden_vectors(name):
     d, kernel, mc = parse_stage_name(name)
@@ -249,7 +308,17 @@ def test_full_size_2d_properties():
     extra, _, _ = ops.backward_backward(None, cG, inp, grid, hO, off, 0, True, False, 0, True)
     assert rel_err(fI, k4I + extra) <= 1e-5
     assert rel_err(fO, k4O) <= 1e-6
-    # 8. a slice of the full-size result against the CPU oracle (n = 5, first 4096 points)
+    # 8. the two GPU paths agree at full size (the direct kernels are the ones checked point by
+    #    point against the oracle above)
+    ops.force_path(1)
+    try:
+        dI, dG = ops.backward(gOut, inp, grid, off, 0, True, True, 0, True)
+        dfI, dfO = ops.bbb_fused(inp, grid, gOut, cG, hG, hO, off, 0, True, 0, True)
+    finally:
+        ops.force_path(0)
+    assert rel_err(gI, dI) <= 1e-5 and rel_err(gG, dG) <= 1e-5
+    assert rel_err(fI, dfI) <= 1e-5 and rel_err(fO, dfO) <= 1e-5
+    # 9. a slice of the full-size result against the CPU oracle (n = 5, first 4096 points)
     sl = slice(0, 4096)
     want = cs_oracle.forward(inp[5:6].cpu(), grid[5:6, :, sl].contiguous().cpu(), off[5:6].cpu(), 0, True, 0, True)
     assert_close(a[5:6, :, :, sl], want, "full-size slice vs oracle")
