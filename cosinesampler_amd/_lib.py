@@ -30,7 +30,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    # COSINESAMPLER_LIB: development override to A/B a differently-built library
+    return os.environ.get("COSINESAMPLER_LIB", _build.LIB)
 
 
 def load():

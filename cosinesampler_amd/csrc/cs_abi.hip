@@ -64,6 +64,14 @@ int zero_async(float *p, int64_t elems, hipStream_t s) {
     return e == hipSuccess ? CS_OK : (int)e;
 }
 
+// channel-count dispatch of the tiled path: CQ = C/4 in {1, 2, 4}
+#define CS_DISPATCH_CQ(C_, ...)                                               \
+    switch (C_) {                                                             \
+        case 4:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
+        case 8:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
+        default: { constexpr int CQ = 4; __VA_ARGS__; } break;                \
+    }
+
 // kernel-enum dispatch: KERNEL is a template parameter so the unused derivative paths fold away
 #define CS_DISPATCH_KERNEL(kernel_enum, ...)                                  \
     switch (kernel_enum) {                                                    \
@@ -134,13 +142,14 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
     int64_t ntx = (W + 1 + tl::TX - 1) / tl::TX, nty = (H + 1 + tl::TY - 1) / tl::TY;
     if (ntx * nty > 12288) return false;                 // tile histogram lives in LDS (48 KiB)
     if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
+    if (N > 65535 || H * W * C >= ((int64_t)1 << 31)) return false;   // gridDim.y = N; 32-bit node offsets
     if (mode == 2) return true;
     return S >= kTiledMinSamples;
 }
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks;
-    size_t off_rank1, off_cell1, off_ord, off_ocell, off_tile_begin, off_block_hist, off_totals, bytes;
+    size_t off_rank, off_sid, off_cell1, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
 };
 
 PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
@@ -151,11 +160,11 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
     int64_t S = N * P;
     size_t o = 0;
-    L.off_rank1 = o;      o += align256((size_t)S * 4);
+    L.off_rank = o;       o += align256((size_t)S * 4);
+    L.off_sid = o;        o += align256((size_t)S * 4);
     L.off_cell1 = o;      o += align256((size_t)S);
-    L.off_ord = o;        o += align256((size_t)S * 4);
-    L.off_ocell = o;      o += align256((size_t)S);
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
+    L.off_cell_begin = o; o += align256((size_t)N * L.ntiles * (tl::CELLS + 1) * 4);
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
     L.bytes = o;
@@ -165,11 +174,11 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
 tl::Plan plan_view(const PlanLayout &L, void *blob) {
     char *b = (char *)blob;
     tl::Plan p;
-    p.rank1 = (uint32_t *)(b + L.off_rank1);
+    p.rank = (uint32_t *)(b + L.off_rank);
+    p.sid = (uint32_t *)(b + L.off_sid);
     p.cell1 = (uint8_t *)(b + L.off_cell1);
-    p.ord = (uint32_t *)(b + L.off_ord);
-    p.ocell = (uint8_t *)(b + L.off_ocell);
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
+    p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
     p.ntx = L.ntx;
     p.nty = L.nty;
@@ -271,6 +280,8 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
     return CS_OK;
 }
 
+dim3 point_grid(const Problem &pb) { return dim3((unsigned)((pb.d.P + kBlock - 1) / kBlock), (unsigned)pb.d.N); }
+
 size_t point_lds(int C, int nrows) { return (size_t)4 * (64 + 64 * nrows * C) * 4; }
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
@@ -279,8 +290,8 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_forward<KERNEL><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                      pr.icl, grid, offset, output, pb.d, pb.f)));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+                                      pr.icl, grid, offset, output, pb.d, pb.f))));
     return launch_status();
 }
 
@@ -301,10 +312,10 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
         rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
-    const uint32_t *rank1 = grad_input ? pr.plan.rank1 : nullptr;
+    const uint32_t *rank = grad_input ? pr.plan.rank : nullptr;
     size_t shm = point_lds(pb.d.C, 1);
-    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_backward<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      gOut, pr.icl, grid, offset, rank1, rows, coef, grad_grid, pb.d, pb.f)));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                                      gOut, pr.icl, grid, offset, rank, rows, coef, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc || !grad_input) return rc;
     return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, grad_input);
@@ -331,9 +342,15 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     size_t shm = point_lds(pb.d.C, 1);
-    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_bb<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank1, rows, coef, gGrid, ggOut,
-                                      pb.d, pb.f)));
+    if (cIcl) {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                                          cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank, rows, coef, gGrid,
+                                          ggOut, pb.d, pb.f))));
+    } else {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                                          cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank, rows, coef, gGrid,
+                                          ggOut, pb.d, pb.f))));
+    }
     rc = launch_status();
     if (rc) return rc;
     return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, gInput);
@@ -354,9 +371,9 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     size_t shm = point_lds(pb.d.C, 2);
-    CS_DISPATCH_KERNEL(pb.kernel, (tl::point_bbb<KERNEL><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank1, rows1, coef1, rows2,
-                                      coef2, ggOut, pb.d, pb.f)));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                                      pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank, rows1, coef1, rows2,
+                                      coef2, ggOut, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     if (hO) return launch_tile_scatter<true>(pb, pr.plan, rows1, coef1, rows2, coef2, gInput);

@@ -37,11 +37,13 @@ __device__ __forceinline__ void kern_eval(float t, float &k0, float &k1, float &
     k1 = 1.0f;
     k2 = 0.0f;
     if (KERNEL == K_COSINE) {
-        // cos(pi t), sin(pi t) with exact-pi argument reduction (the reference multiplies by
-        // float(pi) and, under --use_fast_math, calls __cosf/__sinf: setup.py:37)
-        float c = cospif(t);
+        // cos(pi t), sin(pi t) on the hardware trig unit: v_cos_f32 / v_sin_f32 take their argument
+        // in revolutions, so pi*t is t/2 with no range reduction to get wrong.  Max abs error on
+        // [0,1] measured on MI355X: 1.25e-7 (tools/microbench.hip MB5) -- tighter than the
+        // __cosf/__sinf the reference gets under --use_fast_math (setup.py:37; 2.7e-7).
+        float c = __builtin_amdgcn_cosf(0.5f * t);
         k0 = 0.5f * (1.0f - c);
-        if (ORDER >= 1) k1 = (0.5f * kPi) * sinpif(t);
+        if (ORDER >= 1) k1 = (0.5f * kPi) * __builtin_amdgcn_sinf(0.5f * t);
         if (ORDER >= 2) k2 = (0.5f * kPi * kPi) * c;
     } else if (KERNEL == K_SMOOTHSTEP) {
         k0 = t * t * (3.0f - 2.0f * t);
@@ -52,7 +54,13 @@ __device__ __forceinline__ void kern_eval(float t, float &k0, float &k1, float &
     }
 }
 
+// Coordinate arithmetic is compiled WITHOUT fused multiply-add contraction: t = frac(i) inherits
+// the absolute rounding error of i (one ulp of a coordinate ~ size), and k'(t), k''(t) amplify
+// it, so a contracted and an uncontracted evaluation of the same formula differ by ~1e-5
+// relative at H=W=256.  Evaluated operation by operation -- like the CPU oracle and like
+// torch.nn.functional.grid_sample's own unnormalize -- the source index is bit-reproducible.
 __device__ __forceinline__ float clip_coord(float in, int limit, float &g) {  // 2d.cu:99-116
+#pragma clang fp contract(off)
     if (in <= 0.0f) { g = 0.0f; return 0.0f; }
     float hi = (float)(limit - 1);
     if (in >= hi) { g = 0.0f; return hi; }
@@ -61,6 +69,7 @@ __device__ __forceinline__ float clip_coord(float in, int limit, float &g) {  //
 }
 
 __device__ __forceinline__ float reflect_coord(float in, int twice_low, int twice_high, float &g) {  // 2d.cu:145-171
+#pragma clang fp contract(off)
     if (twice_low == twice_high) { g = 0.0f; return 0.0f; }
     float lo = (float)twice_low * 0.5f;
     float span = (float)(twice_high - twice_low) * 0.5f;
@@ -77,6 +86,7 @@ __device__ __forceinline__ float reflect_coord(float in, int twice_low, int twic
 // source coordinate and mu = d i / d g (2d.cu:212-236)
 __device__ __forceinline__ float source_index(float g, int size, int pad, int align, float off, int multicell,
                                               float &mu) {
+#pragma clang fp contract(off)
     float c;
     if (align) {
         int s = multicell ? size - 1 : size;            // 2d.cu:57-59
@@ -109,6 +119,7 @@ struct Axis {
 
 template <int KERNEL, int ORDER>
 __device__ __forceinline__ Axis make_axis(float g, int size, const Flags &f, int align, float off) {
+#pragma clang fp contract(off)
     Axis a;
     float mu;
     float i = source_index(g, size, f.pad, align, off, f.multicell, mu);

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 def test_native_library_is_the_loaded_one():
     lib = _lib.load()
-    assert lib.cs_abi_version() == 1
+    assert lib.cs_abi_version() == _lib.ABI_VERSION
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Development helper: time each stage of the headline config separately (prepared objects prebuilt),
+plus the plan build and the channels-last pack.  python tools/stage_time.py [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cosinesampler_amd import multicell_offset, ops
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device("cuda", 0)
+N, C, H, P = 16, 16, 256, 1 << 20
+torch.manual_seed(0)
+cells = torch.rand(N, C, H, H, device=dev)
+xy = torch.rand(P, 2, device=dev) * 2 - 1
+grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
+cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
+off = multicell_offset(N, True, dev)
+a = (0, True, 0, True)
+sc = ops.StepContext()
+stages = {
+    "forward": lambda: ops.forward(cells, grid, off, *a, ctx=sc),
+    "backward": lambda: ops.backward(gOut, cells, grid, off, 0, True, True, 0, True, ctx=sc),
+    "backward(no grad_input)": lambda: ops.backward(gOut, cells, grid, off, 0, True, False, 0, True, ctx=sc),
+    "backward_backward": lambda: ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, 0, True, ctx=sc),
+    "bbb_fused": lambda: ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, 0, True, ctx=sc),
+    "plan+pack (fresh ctx fwd+bwd minus above)": None,
+}
+for name, fn in stages.items():
+    if fn is None:
+        continue
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print("%-28s %8.3f ms" % (name, e0.elapsed_time(e1) / reps), flush=True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    c2 = ops.StepContext()
+    lib = ops._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    c2.input_cl(lib, cells, 2, [N, C, H, H], P, st)
+    c2.plan(lib, grid, off, 2, [N, C, H, H], P, 0, True, True, st)
+e1.record()
+torch.cuda.synchronize()
+print("%-28s %8.3f ms" % ("pack + plan build", e0.elapsed_time(e1) / reps))
