@@ -149,7 +149,7 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks;
-    size_t off_rank, off_sid, off_cell1, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
+    size_t off_sorted, off_sid, off_cell1, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
 };
 
 PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
@@ -160,7 +160,7 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
     int64_t S = N * P;
     size_t o = 0;
-    L.off_rank = o;       o += align256((size_t)S * 4);
+    L.off_sorted = o;     o += align256((size_t)S * 4);
     L.off_sid = o;        o += align256((size_t)S * 4);
     L.off_cell1 = o;      o += align256((size_t)S);
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
@@ -174,7 +174,7 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
 tl::Plan plan_view(const PlanLayout &L, void *blob) {
     char *b = (char *)blob;
     tl::Plan p;
-    p.rank = (uint32_t *)(b + L.off_rank);
+    p.sorted = (uint32_t *)(b + L.off_sorted);
     p.sid = (uint32_t *)(b + L.off_sid);
     p.cell1 = (uint8_t *)(b + L.off_cell1);
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
@@ -230,21 +230,14 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     if (stage == CS_STAGE_FORWARD) return need;
     if (!have_plan) need += plan_layout(N, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    size_t rows = align256(S * C * 4), coef = align256(S * 16);
-    need += rows + coef;
-    if (stage == CS_STAGE_BBB_FUSED) need += rows + coef;
+    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : C + 4) * 4);   // fat rows
     return need;
 }
 
 template <bool TWO>
-int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *rows1, const float4 *coef1,
-                        const float *rows2, const float4 *coef2, float *grad_input) {
+int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *fat, float *grad_input) {
     unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntiles);
-    switch (pb.d.C) {
-        case 4: tl::tile_scatter<2, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
-        case 8: tl::tile_scatter<3, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
-        default: tl::tile_scatter<4, TWO><<<nb, 256, 0, pb.stream>>>(rows1, coef1, rows2, coef2, pl, grad_input, pb.d); break;
-    }
+    CS_DISPATCH_CQ(pb.d.C, (tl::tile_scatter<CQ, TWO><<<nb, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
     return launch_status();
 }
 
@@ -282,7 +275,8 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
 
 dim3 point_grid(const Problem &pb) { return dim3((unsigned)((pb.d.P + kBlock - 1) / kBlock), (unsigned)pb.d.N); }
 
-size_t point_lds(int C, int nrows) { return (size_t)4 * (64 + 64 * nrows * C) * 4; }
+size_t fat_lds(int C, bool two) { return (size_t)256 * (two ? 2 * C + 8 : C + 4) * 4; }   // 4 waves x 64 fat rows
+size_t point_lds() { return (size_t)4 * tl::REC_FLOATS * 4; }   // one geometry record block per wave
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
                   const float *input_cl, void *workspace, size_t workspace_bytes) {
@@ -290,7 +284,7 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds(), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
     return launch_status();
 }
@@ -300,25 +294,21 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
                    size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
-    // without grad_input nothing is scattered: no plan, no rows
+    // without grad_input nothing is scattered: no plan, no fat rows
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *rows = nullptr;
-    float4 *coef = nullptr;
+    float *fat = nullptr;
     if (grad_input) {
-        rows = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
-        coef = (float4 *)ws.take((size_t)pb.d.S * 16);
+        fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
-    const uint32_t *rank = grad_input ? pr.plan.rank : nullptr;
-    size_t shm = point_lds(pb.d.C, 1);
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                      gOut, pr.icl, grid, offset, rank, rows, coef, grad_grid, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+                                      gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc || !grad_input) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, grad_input);
+    return launch_tile_scatter<false>(pb, pr.plan, fat, grad_input);
 }
 
 int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
@@ -336,24 +326,20 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         if (rc) return rc;
         cIcl = buf;
     }
-    float *rows = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
-    float4 *coef = (float4 *)ws.take((size_t)pb.d.S * 16);
+    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    size_t shm = point_lds(pb.d.C, 1);
     if (cIcl) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                          cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank, rows, coef, gGrid,
-                                          ggOut, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+                                          cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                          cIcl, cG, pr.icl, grid, gOut, offset, pr.plan.rank, rows, coef, gGrid,
-                                          ggOut, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+                                          cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     }
     rc = launch_status();
     if (rc) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, rows, coef, nullptr, nullptr, gInput);
+    return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
 }
 
 int tiled_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
@@ -363,21 +349,22 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *rows1 = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
-    float4 *coef1 = (float4 *)ws.take((size_t)pb.d.S * 16);
-    float *rows2 = (float *)ws.take((size_t)pb.d.S * pb.d.C * 4);
-    float4 *coef2 = (float4 *)ws.take((size_t)pb.d.S * 16);
+    float *fat = (float *)ws.take((size_t)pb.d.S * (2 * pb.d.C + 8) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    size_t shm = point_lds(pb.d.C, 2);
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                      pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank, rows1, coef1, rows2,
-                                      coef2, ggOut, pb.d, pb.f))));
+    if (hO) {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, fat_lds(pb.d.C, true), pb.stream>>>(
+                                          pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
+        rc = launch_status();
+        if (rc) return rc;
+        return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
+    }
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+                                      pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
-    if (hO) return launch_tile_scatter<true>(pb, pr.plan, rows1, coef1, rows2, coef2, gInput);
-    return launch_tile_scatter<false>(pb, pr.plan, rows1, coef1, nullptr, nullptr, gInput);
+    return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
 }
 
 bool any_null(std::initializer_list<const void *> ps) {

@@ -9,19 +9,22 @@
 //   * random 4 x 64 B node gathers from a channels-last table run at ~12.5 TB/s (L2->L1 bound).
 //
 // Structure of one backward stage (grad_input part):
-//   plan   (once per grid)  sort samples by (n, 16x16-cell tile, cell): final slot `rank[s]`, first
-//                           slot of every tile (`tile_begin`) and of every cell in it (`cell_begin`).
-//   point kernel (p-order)  one lane per sample, streams coalesced, node vectors gathered from
-//                           the channels-last copy of `input`; computes every p-ordered output
-//                           (grad_grid / ggOut / ...) and writes, per sample, a 64-byte payload
-//                           row (the C cotangent values) plus a 16-byte coefficient record
-//                           (4 node weights) into its tile-sorted slot.
-//   tile kernel ("walkers") one workgroup per (n, tile); 16 lanes = the C channels of one
-//                           walker, one walker per cell row of the tile.  A walker visits its
-//                           samples in cell order, keeps the 4 node sums of the current cell in
-//                           registers, hands the right-hand pair to the next cell (shared nodes)
-//                           and stores finished node sums to LDS without atomics; the tile's
-//                           (TX+1)x(TY+1) nodes are then added to grad_input (NCHW), lanes along x.
+//   plan   (once per grid)  sort the samples by (n, 16x16-cell tile, cell): `sorted[j]` = sample id
+//                           at sorted position j, first position of every tile (`tile_begin`) and
+//                           of every cell in it (`cell_begin`).
+//   point kernel (p-order)  one lane per sample, every stream access coalesced, node vectors
+//                           gathered from the channels-last copy of `input`; computes every
+//                           p-ordered output (grad_grid / ggOut / ...) and leaves, per sample, one
+//                           contiguous "fat row" in p-order: the C cotangent values followed by the
+//                           4 node coefficients (third backward: two of each).  Sequential writes.
+//   tile kernel ("walkers") one workgroup per (n, tile); C/4 lanes form a walker (one float4 of
+//                           channels each), one walker per run of C/4 cells of one cell row.  A
+//                           walker visits its samples in cell order -- fetching their fat rows by
+//                           sample id, the only random access of the stage, ~80-160 contiguous
+//                           bytes each --, keeps the 4 node sums of the current cell in registers,
+//                           hands the right-hand pair to the next cell (shared nodes) and stores
+//                           finished node sums to LDS without atomics; the tile's (TX+1)x(TY+1)
+//                           nodes are then added to grad_input (NCHW), lanes along x.
 //
 // Reference maths per stage: see cs_kernels_direct.cuh (same formulas, same quirks).
 #pragma once
@@ -36,11 +39,12 @@ constexpr int CHUNK = 4096;                // samples per plan workgroup
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
 struct Plan {
-    uint32_t *rank;        // [S]  sample -> final slot: sorted by (n, tile, cell)  (INVALID: touches no node)
-    uint32_t *sid;         // [S]  scratch: tile-sorted slot -> sample
+    uint32_t *sorted;      // [S]  sorted position (by n, tile, cell) -> sample id n*P+p; only the first
+                           //      tile_begin[N*ntiles] entries are defined (samples touching no node are dropped)
+    uint32_t *sid;         // [S]  scratch: tile-sorted slot -> sample id
     uint8_t *cell1;        // [S]  scratch: tile-sorted slot -> local cell id
-    uint32_t *tile_begin;  // [N*ntiles + 1]      first slot of every tile bucket
-    uint32_t *cell_begin;  // [N*ntiles*(CELLS+1)] bucket-relative first slot of every cell of every tile
+    uint32_t *tile_begin;  // [N*ntiles + 1]      first sorted position of every tile bucket
+    uint32_t *cell_begin;  // [N*ntiles*(CELLS+1)] bucket-relative first position of every cell of every tile
     uint32_t *block_hist;  // [N*chunks*ntiles] scratch
     int ntx, nty, ntiles, chunks;
 };
@@ -177,14 +181,12 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
                 uint32_t r = atomicAdd(&cursor[q.tile], 1u);
                 pl.cell1[r] = (uint8_t)q.cell;
                 pl.sid[r] = (uint32_t)s;
-            } else {
-                pl.rank[s] = INVALID;
             }
         }
     }
 }
 
-// one workgroup per (n, tile): counting sort of the bucket by local cell id -> final slots
+// one workgroup per (n, tile): counting sort of the bucket by local cell id -> final order
 __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl) {
     __shared__ uint32_t cnt[CELLS];
     __shared__ uint32_t scan[CELLS];
@@ -211,14 +213,18 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl) {
     __syncthreads();
     for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) {
         uint32_t pos = atomicAdd(&cnt[pl.cell1[j]], 1u);
-        pl.rank[pl.sid[j]] = b0 + pos;
+        pl.sorted[b0 + pos] = pl.sid[j];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// point kernels: one lane per sample, channels-last gathers, payload rows to tile-sorted slots.
-// Launch: grid (ceil(P/256), N), 256 threads; CQ = C/4 is a template parameter so that every
-// gather of a sample (4 nodes x CQ float4) is in flight before the first one is consumed.
+// point kernels.  Launch: grid (ceil(P/256), N), 256 threads; a wave owns 64 consecutive points of
+// one n.  Two phases per wave:
+//   1. lane = sample: coordinates, weights, derivatives  ->  a small record in LDS;
+//   2. lane = (sample, channel quad): CQ = C/4 lanes share a sample, so one wave instruction
+//      fetches 64/CQ whole 16*CQ-byte node vectors (the L1 sees each node line once instead of
+//      CQ times), the payload row of a sample leaves as one contiguous 16*CQ-byte store, and the
+//      channel sums for grad_grid are finished with CQ-lane shuffles.
 // ------------------------------------------------------------------------------------------------
 // Stream accesses (each element touched once per kernel) are marked nontemporal so that they do
 // not displace the feature table from L2 / Infinity Cache.
@@ -240,34 +246,176 @@ __device__ __forceinline__ float ld_stream(const float *p) {
 #endif
 }
 
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// record fields (one float/uint per sample, SoA over the wave's 64 samples)
+enum { R_NODE = 0, R_WX0 = 4, R_WX1, R_WY0, R_WY1, R_D1X, R_D1Y, R_D2X, R_D2Y, R_SLOT, R_CGX, R_CGY, R_HGX, R_HGY,
+       R_FIELDS };
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+constexpr int REC_FLOATS = R_FIELDS * 64;   // per wave
+
+// phase 1: lane = sample.  Returns nothing; everything phase 2 needs is in `rec`.
+template <int KERNEL, int ORDER>
+__device__ __forceinline__ void point_phase1(float *rec, const float *grid, const float *offset,
+                                             const uint32_t *rank, const float *cG, const float *hG, const Dims &d,
+                                             const Flags &f, int align) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.y;
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < d.P;
+    if (!live) p = d.P - 1;
+    const int64_t s = (int64_t)n * d.P + p;
+    const float off = offset[n];
+    float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
+    Axis ax = make_axis<KERNEL, ORDER>(g.x, d.size[0], f, align, off);
+    Axis ay = make_axis<KERNEL, ORDER>(g.y, d.size[1], f, align, off);
+    uint32_t *ru = reinterpret_cast<uint32_t *>(rec);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        int x = ax.lo + (a & 1), y = ay.lo + (a >> 1);
+        bool ok = x >= 0 && x < d.size[0] && y >= 0 && y < d.size[1];
+        ru[(R_NODE + a) * 64 + lane] = ok ? (uint32_t)(y * d.size[0] + x) : NO_NODE;
+    }
+    rec[R_WX0 * 64 + lane] = ax.w[0];
+    rec[R_WX1 * 64 + lane] = ax.w[1];
+    rec[R_WY0 * 64 + lane] = ay.w[0];
+    rec[R_WY1 * 64 + lane] = ay.w[1];
+    if (ORDER >= 1) {
+        rec[R_D1X * 64 + lane] = ax.d1;
+        rec[R_D1Y * 64 + lane] = ay.d1;
+    }
+    if (ORDER >= 2) {
+        rec[R_D2X * 64 + lane] = ax.d2;
+        rec[R_D2Y * 64 + lane] = ay.d2;
+    }
+    ru[R_SLOT * 64 + lane] = (live && rank) ? rank[s] : INVALID;
+    if (cG) {
+        float2 c = *reinterpret_cast<const float2 *>(cG + s * 2);
+        rec[R_CGX * 64 + lane] = c.x;
+        rec[R_CGY * 64 + lane] = c.y;
+    } else if (ORDER >= 2) {
+        rec[R_CGX * 64 + lane] = 0.f;
+        rec[R_CGY * 64 + lane] = 0.f;
+    }
+    if (hG) {
+        float2 h = *reinterpret_cast<const float2 *>(hG + s * 2);
+        rec[R_HGX * 64 + lane] = h.x;
+        rec[R_HGY * 64 + lane] = h.y;
+    } else if (ORDER >= 2) {
+        rec[R_HGX * 64 + lane] = 0.f;
+        rec[R_HGY * 64 + lane] = 0.f;
+    }
+}
+
+// what a phase-2 lane knows about its sample
+struct QuadSample {
+    int sl;            // sample slot inside the wave (0..63)
+    int q;             // channel quad
+    int64_t p;         // point index inside n (valid only if live)
+    bool live;
+    uint32_t node[4];
+    float wx[2], wy[2];
+    float W[4];
+    __device__ __forceinline__ void read(const float *rec, int sub, int CQ, const Dims &d) {
+        const int lane = threadIdx.x & 63;
+        const int per = 64 / CQ;
+        sl = sub * per + lane / CQ;
+        q = lane % CQ;
+        p = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63) + sl;
+        live = p < d.P;
+        const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) node[a] = ru[(R_NODE + a) * 64 + sl];
+        wx[0] = rec[R_WX0 * 64 + sl];
+        wx[1] = rec[R_WX1 * 64 + sl];
+        wy[0] = rec[R_WY0 * 64 + sl];
+        wy[1] = rec[R_WY1 * 64 + sl];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) W[a] = wx[a & 1] * wy[a >> 1];
+    }
+};
+
+template <int CQ>
+__device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs, float4 (&v)[4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = tab[(qs.node[a] == NO_NODE ? 0u : qs.node[a]) * CQ + qs.q];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (qs.node[a] == NO_NODE) v[a] = zero4();
+}
+__device__ __forceinline__ float4 load_quad(const float *src, int64_t P) {
+    return make_float4(ld_stream(src), ld_stream(src + P), ld_stream(src + 2 * P), ld_stream(src + 3 * P));
+}
+__device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o) {
+    st_stream(dst, o.x);
+    st_stream(dst + P, o.y);
+    st_stream(dst + 2 * P, o.z);
+    st_stream(dst + 3 * P, o.w);
+}
+// sum over the CQ lanes of a sample (lanes of one sample are adjacent)
+template <int CQ>
+__device__ __forceinline__ float quad_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < CQ; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int KERNEL, int CQ>
+__global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
+                                                     const float *__restrict__ offset, float *__restrict__ out,
+                                                     Dims d, Flags f) {
+    extern __shared__ float lds[];
+    constexpr int C = 4 * CQ;
+    float *rec = lds + (threadIdx.x >> 6) * REC_FLOATS;
+    point_phase1<KERNEL, 0>(rec, grid, offset, nullptr, nullptr, nullptr, d, f, 1);  // 2D fwd: align = 1 (2d.cu:307-308)
+    __syncthreads();
+    const int n = blockIdx.y;
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
+    float *obase = out + (int64_t)n * C * d.P;
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) {
+        QuadSample qs;
+        qs.read(rec, sub, CQ, d);
+        float4 v[4];
+        gather4<CQ>(tab, qs, v);
+        float4 acc = zero4();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc = fma4(qs.W[a], v[a], acc);
+        if (qs.live) store_quad(obase + (int64_t)(4 * qs.q) * d.P + qs.p, d.P, acc);
+    }
+}
+
+// ---- backward point kernels: lane = sample (every stream access is 256 contiguous bytes per wave) ----
 struct Sample2 {
     int n;
     int64_t p, s;
+    bool live;
     Axis ax[2];
-    uint32_t node[4];  // node index (y*W + x) inside one n; 0 when zero-padded (see ok[])
-    bool ok[4];
+    uint32_t node[4];  // node index (y*W + x) inside one n; NO_NODE when zero-padded
     float W[4];
 
     template <int KERNEL, int ORDER>
-    __device__ __forceinline__ bool load(const float *grid, const float *offset, const Dims &d, const Flags &f,
-                                         int align) {
+    __device__ __forceinline__ void load(const float *grid, const float *offset, const Dims &d, const Flags &f) {
         n = blockIdx.y;
         int64_t pp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        bool live = pp < d.P;
-        p = live ? pp : d.P - 1;           // keep every lane of the wave busy: cooperative row writes follow
+        live = pp < d.P;
+        p = live ? pp : d.P - 1;
         s = (int64_t)n * d.P + p;
         float off = offset[n];
         float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
-        ax[0] = make_axis<KERNEL, ORDER>(g.x, d.size[0], f, align, off);
-        ax[1] = make_axis<KERNEL, ORDER>(g.y, d.size[1], f, align, off);
+        ax[0] = make_axis<KERNEL, ORDER>(g.x, d.size[0], f, f.align, off);
+        ax[1] = make_axis<KERNEL, ORDER>(g.y, d.size[1], f, f.align, off);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             int x = ax[0].lo + (a & 1), y = ax[1].lo + (a >> 1);
-            ok[a] = x >= 0 && x < d.size[0] && y >= 0 && y < d.size[1];
-            node[a] = ok[a] ? (uint32_t)(y * d.size[0] + x) : 0u;
+            bool ok = x >= 0 && x < d.size[0] && y >= 0 && y < d.size[1];
+            node[a] = ok ? (uint32_t)(y * d.size[0] + x) : NO_NODE;
             W[a] = ax[0].w[a & 1] * ax[1].w[a >> 1];
         }
-        return live;
     }
     __device__ __forceinline__ float first(int a, int j) const {
         float sgn = ((a >> j) & 1) ? ax[j].d1 : -ax[j].d1;
@@ -279,109 +427,78 @@ struct Sample2 {
     }
 };
 
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
-    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
-}
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-
 // all 4*CQ node vectors of a sample; zero-padded nodes read node 0 and are masked afterwards
 template <int CQ>
 __device__ __forceinline__ void gather_nodes(const float4 *tab, const Sample2 &sm, float4 (&v)[4][CQ]) {
+#ifdef CS_DBG_NO_GATHER
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < CQ; ++q) v[a][q] = tab[sm.node[a] * CQ + q];
+        for (int q = 0; q < CQ; ++q) v[a][q] = make_float4(sm.W[a], sm.W[a] + q, 1.f, 2.f);
+    return;
+#endif
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) v[a][q] = tab[(sm.node[a] == NO_NODE ? 0u : sm.node[a]) * CQ + q];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int q = 0; q < CQ; ++q)
-            if (!sm.ok[a]) v[a][q] = zero4();
+            if (sm.node[a] == NO_NODE) v[a][q] = zero4();
 }
-
 template <int CQ>
 __device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 (&g)[CQ]) {
+#ifdef CS_DBG_NO_GLOAD
 #pragma unroll
-    for (int q = 0; q < CQ; ++q)
-        g[q] = make_float4(ld_stream(src + (4 * q) * P), ld_stream(src + (4 * q + 1) * P),
-                           ld_stream(src + (4 * q + 2) * P), ld_stream(src + (4 * q + 3) * P));
+    for (int q = 0; q < CQ; ++q) g[q] = make_float4((float)P, (float)q, 1.f, 2.f);
+    return;
+#endif
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) g[q] = load_quad(src + (int64_t)(4 * q) * P, P);
 }
 template <int CQ>
 __device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4 (&o)[CQ]) {
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        st_stream(dst + (4 * q) * P, o[q].x);
-        st_stream(dst + (4 * q + 1) * P, o[q].y);
-        st_stream(dst + (4 * q + 2) * P, o[q].z);
-        st_stream(dst + (4 * q + 3) * P, o[q].w);
-    }
+    for (int q = 0; q < CQ; ++q) store_quad(dst + (int64_t)(4 * q) * P, P, o[q]);
 }
-
-// Cooperative write of one wave's 64 payload rows (C floats each) staged in LDS as stage[row][C]:
-// consecutive lanes write consecutive 16-byte pieces, so each row goes out as whole 64-byte sectors.
+// fat row of sample s: payload(s) then coefficient record(s), contiguous, 16-byte aligned.
+// A lane first puts its row into the wave's LDS stage; flush_rows then streams the wave's 64 rows
+// (one contiguous 64*STRIDE*4-byte block of the p-ordered array) with consecutive lanes writing
+// consecutive 16-byte pieces -- a lane-strided struct store would touch every line 5-10 times.
 template <int CQ>
-__device__ __forceinline__ void write_rows(const float *stage, const uint32_t *slots, float *rows) {
+__device__ __forceinline__ void put_payload(float *row, const float4 (&g)[CQ]) {
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) *reinterpret_cast<float4 *>(row + 4 * q) = g[q];
+}
+template <int STRIDE>
+__device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n, const Dims &d) {
     const int lane = threadIdx.x & 63;
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first point of this wave
+    if (p0 >= d.P) return;
+    const int nlive = (int)min((int64_t)64, d.P - p0);
+    float4 *dst = reinterpret_cast<float4 *>(fat + ((int64_t)n * d.P + p0) * STRIDE);
+    const float4 *src = reinterpret_cast<const float4 *>(stage);
+    constexpr int PIECES = STRIDE / 4;                                        // float4 per row
 #pragma unroll
-    for (int i = 0; i < CQ; ++i) {
+    for (int i = 0; i < PIECES; ++i) {
         int item = i * 64 + lane;
-        int r = item / CQ, k = item % CQ;
-        uint32_t slot = slots[r];
-        if (slot != INVALID) {
-            float4 v = *reinterpret_cast<const float4 *>(stage + r * (4 * CQ) + 4 * k);
-            *reinterpret_cast<float4 *>(rows + (int64_t)slot * (4 * CQ) + 4 * k) = v;
-        }
+        if (item < nlive * PIECES) dst[item] = src[item];
     }
 }
-template <int CQ>
-__device__ __forceinline__ void stage_row(float *stage, int lane, const float4 (&g)[CQ]) {
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) *reinterpret_cast<float4 *>(stage + lane * (4 * CQ) + 4 * q) = g[q];
-}
 
-template <int KERNEL, int CQ>
-__global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
-                                                     const float *__restrict__ offset, float *__restrict__ out,
-                                                     Dims d, Flags f) {
-    constexpr int C = 4 * CQ;
-    Sample2 sm;
-    if (!sm.load<KERNEL, 0>(grid, offset, d, f, 1)) return;   // 2D forward: align_corners = 1 (2d.cu:307-308)
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float4 v[4][CQ];
-    gather_nodes<CQ>(tab, sm, v);
-    float4 o[CQ];
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        float4 acc = zero4();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc = fma4(sm.W[a], v[a][q], acc);
-        o[q] = acc;
-    }
-    store_stream<CQ>(out + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
-}
-
-// LDS of the point kernels: per wave  slots[64] + NROWS * stage[64][C]
 template <int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ gOut, const float *__restrict__ icl,
                                                       const float *__restrict__ grid, const float *__restrict__ offset,
-                                                      const uint32_t *__restrict__ rank, float *__restrict__ rows,
-                                                      float4 *__restrict__ coef, float *__restrict__ grad_grid,
+                                                      float *__restrict__ fat, float *__restrict__ grad_grid,
                                                       Dims d, Flags f) {
-    extern __shared__ float lds[];
-    constexpr int C = 4 * CQ;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *stage = lds + wave * (64 + 64 * C);
-    uint32_t *slots = reinterpret_cast<uint32_t *>(stage);
-    stage += 64;
+    constexpr int C = 4 * CQ, STRIDE = C + 4;
     Sample2 sm;
-    bool live = sm.load<KERNEL, 1>(grid, offset, d, f, f.align);
-    uint32_t slot = (live && rows) ? rank[sm.s] : INVALID;
-    slots[lane] = slot;
+    sm.load<KERNEL, 1>(grid, offset, d, f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float4 g[CQ], v[4][CQ];
     load_stream<CQ>(gOut + (int64_t)sm.n * C * d.P + sm.p, d.P, g);
     gather_nodes<CQ>(tab, sm, v);
-    // d/dx: -/+ on the x side weighted by the y weights; d/dy likewise
     const float wy0 = sm.ax[1].w[0], wy1 = sm.ax[1].w[1], wx0 = sm.ax[0].w[0], wx1 = sm.ax[0].w[1];
     float gx = 0.f, gy = 0.f;
 #pragma unroll
@@ -390,35 +507,28 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
         gx += wy0 * (d1 - d0) + wy1 * (d3 - d2);
         gy += wx0 * (d2 - d0) + wx1 * (d3 - d1);
     }
-    if (live) {
-        *reinterpret_cast<float2 *>(grad_grid + sm.s * 2) = make_float2(sm.ax[0].d1 * gx, sm.ax[1].d1 * gy);
-        if (slot != INVALID) coef[slot] = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
-    }
-    if (rows) {
-        stage_row<CQ>(stage, lane, g);
+    if (sm.live) *reinterpret_cast<float2 *>(grad_grid + sm.s * 2) = make_float2(sm.ax[0].d1 * gx, sm.ax[1].d1 * gy);
+    if (fat) {
+        extern __shared__ float lds[];
+        float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
+        float *row = stage + (threadIdx.x & 63) * STRIDE;
+        put_payload<CQ>(row, g);
+        *reinterpret_cast<float4 *>(row + C) = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
         __syncthreads();
-        write_rows<CQ>(stage, slots, rows);
+        flush_rows<STRIDE>(stage, fat, sm.n, d);
     }
 }
 
-// second backward, point part.  cIcl = channels-last copy of gOutInput (nullable).
+// second backward, point part.  cIcl = channels-last copy of gOutInput (HAS_CI).
 template <int KERNEL, int CQ, bool HAS_CI>
 __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                 const float *__restrict__ icl, const float *__restrict__ grid,
                                                 const float *__restrict__ gOut, const float *__restrict__ offset,
-                                                const uint32_t *__restrict__ rank, float *__restrict__ rows,
-                                                float4 *__restrict__ coef, float *__restrict__ gGrid,
+                                                float *__restrict__ fat, float *__restrict__ gGrid,
                                                 float *__restrict__ ggOut, Dims d, Flags f) {
-    extern __shared__ float lds[];
-    constexpr int C = 4 * CQ;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *stage = lds + wave * (64 + 64 * C);
-    uint32_t *slots = reinterpret_cast<uint32_t *>(stage);
-    stage += 64;
+    constexpr int C = 4 * CQ, STRIDE = C + 4;
     Sample2 sm;
-    bool live = sm.load<KERNEL, 2>(grid, offset, d, f, f.align);
-    uint32_t slot = live ? rank[sm.s] : INVALID;
-    slots[lane] = slot;
+    sm.load<KERNEL, 2>(grid, offset, d, f);
     float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float4 g[CQ], v[4][CQ];
@@ -455,36 +565,29 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
 #pragma unroll
             for (int a = 0; a < 4; ++a) o[q] = fma4(sm.W[a], u[a][q], o[q]);
     }
-    if (live) {
+    if (sm.live) {
         store_stream<CQ>(ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
         *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(sx, sy);
-        if (slot != INVALID) coef[slot] = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
     }
-    stage_row<CQ>(stage, lane, g);
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
+    float *row = stage + (threadIdx.x & 63) * STRIDE;
+    put_payload<CQ>(row, g);
+    *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
     __syncthreads();
-    write_rows<CQ>(stage, slots, rows);
+    flush_rows<STRIDE>(stage, fat, sm.n, d);
 }
 
-// fused third backward, point part: rows1/coef1 carry (gOut, E), rows2/coef2 carry (hO, D)
-template <int KERNEL, int CQ>
+// fused third backward, point part.  Fat row: TWO ? [gOut | hO | E | D] : [gOut | E]
+template <int KERNEL, int CQ, bool TWO>
 __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, const float *__restrict__ grid,
                                                  const float *__restrict__ gOut, const float *__restrict__ cG,
                                                  const float *__restrict__ hG, const float *__restrict__ hO,
-                                                 const float *__restrict__ offset, const uint32_t *__restrict__ rank,
-                                                 float *__restrict__ rows1, float4 *__restrict__ coef1,
-                                                 float *__restrict__ rows2, float4 *__restrict__ coef2,
+                                                 const float *__restrict__ offset, float *__restrict__ fat,
                                                  float *__restrict__ ggOut, Dims d, Flags f) {
-    extern __shared__ float lds[];
-    constexpr int C = 4 * CQ;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *stage1 = lds + wave * (64 + 128 * C);
-    uint32_t *slots = reinterpret_cast<uint32_t *>(stage1);
-    stage1 += 64;
-    float *stage2 = stage1 + 64 * C;
+    constexpr int C = 4 * CQ, STRIDE = TWO ? 2 * C + 8 : C + 4;
     Sample2 sm;
-    bool live = sm.load<KERNEL, 2>(grid, offset, d, f, f.align);
-    uint32_t slot = live ? rank[sm.s] : INVALID;
-    slots[lane] = slot;
+    sm.load<KERNEL, 2>(grid, offset, d, f);
     float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
     float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
@@ -505,39 +608,42 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         for (int a = 0; a < 4; ++a) acc = fma4(Em[a], v[a][q], acc);
         o[q] = acc;
     }
-    if (live) {
-        store_stream<CQ>(ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
-        if (slot != INVALID) {
-            coef1[slot] = make_float4(Em[0], Em[1], Em[2], Em[3]);
-            if (hO) coef2[slot] = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
-        }
-    }
-    stage_row<CQ>(stage1, lane, g);
-    if (hO) {
+    if (sm.live) store_stream<CQ>(ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
+    float *row = stage + (threadIdx.x & 63) * STRIDE;
+    put_payload<CQ>(row, g);
+    if (TWO) {
         float4 h[CQ];
         load_stream<CQ>(hO + (int64_t)sm.n * C * d.P + sm.p, d.P, h);
-        stage_row<CQ>(stage2, lane, h);
+        put_payload<CQ>(row + C, h);
+        *reinterpret_cast<float4 *>(row + 2 * C) = make_float4(Em[0], Em[1], Em[2], Em[3]);
+        *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
+    } else {
+        *reinterpret_cast<float4 *>(row + C) = make_float4(Em[0], Em[1], Em[2], Em[3]);
     }
     __syncthreads();
-    write_rows<CQ>(stage1, slots, rows1);
-    if (hO) write_rows<CQ>(stage2, slots, rows2);
+    flush_rows<STRIDE>(stage, fat, sm.n, d);
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile kernel: grad_input[n,c,node] += sum over the tile's samples of coef_a * row[c]
-// one workgroup per (n, tile); C lanes per walker; walker w owns cell rows w, w+NW, ...
+// tile kernel: grad_input[n,c,node] += sum over the tile's samples of coef_a * payload[c]
+// one workgroup per (n, tile).  CQ lanes = one walker (lane q owns channels 4q..4q+3); walker
+// (ly, seg) owns cells [seg*CQ, (seg+1)*CQ) of cell row ly: 256/CQ walkers = TY rows x TX/CQ runs.
 // ------------------------------------------------------------------------------------------------
-template <int LOGC, bool TWO>
-__global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ rows1, const float4 *__restrict__ coef1,
-                                                    const float *__restrict__ rows2, const float4 *__restrict__ coef2,
-                                                    Plan pl, float *__restrict__ grad_input, Dims d) {
-    constexpr int C = 1 << LOGC;
-    constexpr int NW = 256 >> LOGC;            // walkers per workgroup
-    constexpr int NS = C + 1;                  // padded node stride (floats) in LDS
+template <int CQ, bool TWO>
+__global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fat, Plan pl,
+                                                    float *__restrict__ grad_input, Dims d) {
+    constexpr int C = 4 * CQ;
+    constexpr int STRIDE = TWO ? 2 * C + 8 : C + 4;
+    constexpr int SEGW = CQ;                   // cells per walker
+    constexpr int NSEG = TX / SEGW;            // walkers per cell row
+    constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
     constexpr int U = 4;                       // samples in flight per walker
-    __shared__ float top[TY * (TX + 1) * NS];  // node sums seen from the cell row below-right / above
-    __shared__ float bot[TY * (TX + 1) * NS];
-    __shared__ uint32_t cb[CELLS + 1];         // bucket-relative first slot of every cell
+    static_assert(TY * NSEG * CQ == 256, "one workgroup = all walkers of a tile");
+    __shared__ float4 top[TY * NODES * CQ];    // sums for the nodes on the low-y side of each cell row
+    __shared__ float4 bot[TY * NODES * CQ];    // ... on the high-y side
+    __shared__ uint32_t cb[CELLS + 1];         // bucket-relative first position of every cell
 
     const int64_t t = blockIdx.x;
     const uint32_t b0 = pl.tile_begin[t], b1 = pl.tile_begin[t + 1];
@@ -551,75 +657,86 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ ro
     }
     __syncthreads();
 
-    const int w = threadIdx.x >> LOGC, c = threadIdx.x & (C - 1);
-    for (int ly = w; ly < TY; ly += NW) {
-        float ct = 0.f, cbm = 0.f;             // sums carried to the next cell: its left nodes are our right nodes
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int cur = 0;                           // current local x
-        float *trow = top + ly * (TX + 1) * NS + c;
-        float *brow = bot + ly * (TX + 1) * NS + c;
-        const uint32_t *cbr = cb + ly * TX;
-        const uint32_t j1 = cbr[TX];
-        uint32_t nb = cbr[1];                  // first slot of the next cell
+    const int w = threadIdx.x / CQ, q = threadIdx.x % CQ;
+    const int ly = w / NSEG, seg = w % NSEG;
+    {
+        float4 ct = zero4(), cbm = zero4();     // sums carried to the next cell: its left nodes are our right nodes
+        float4 a0 = zero4(), a1 = zero4(), a2 = zero4(), a3 = zero4();
+        int cur = 0;                            // current cell of the run
+        float4 *trow = top + ((ly * NSEG + seg) * (SEGW + 1)) * CQ + q;
+        float4 *brow = bot + ((ly * NSEG + seg) * (SEGW + 1)) * CQ + q;
+        const uint32_t *cbr = cb + ly * TX + seg * SEGW;
+        const uint32_t j1 = cbr[SEGW];
+        uint32_t nb = cbr[1];                   // first position of the next cell
+        const uint32_t *sorted = pl.sorted + b0;
         for (uint32_t j = cbr[0]; j < j1; j += U) {
-            float4 k[U], k2[U];
-            float g[U], h[U];
+            float4 g[U], k[U], h[U], k2[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {      // all loads of the batch first: the slots are consecutive
-                uint32_t r = b0 + min(j + u, j1 - 1);
-                k[u] = coef1[r];
-                g[u] = rows1[(int64_t)r * C + c];
+            for (int u = 0; u < U; ++u) {       // all loads of the batch first
+                const float *row = fat + (int64_t)sorted[min(j + u, j1 - 1)] * STRIDE;
+                g[u] = *reinterpret_cast<const float4 *>(row + 4 * q);
                 if (TWO) {
-                    k2[u] = coef2[r];
-                    h[u] = rows2[(int64_t)r * C + c];
+                    h[u] = *reinterpret_cast<const float4 *>(row + C + 4 * q);
+                    k[u] = *reinterpret_cast<const float4 *>(row + 2 * C);
+                    k2[u] = *reinterpret_cast<const float4 *>(row + 2 * C + 4);
+                } else {
+                    k[u] = *reinterpret_cast<const float4 *>(row + C);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (j + u < j1) {
-                    while (j + u >= nb) {      // close cells up to the one holding this slot
-                        trow[cur * NS] = ct + a0;
-                        brow[cur * NS] = cbm + a2;
+                    while (j + u >= nb) {       // close cells up to the one holding this position
+                        trow[cur * CQ] = make_float4(ct.x + a0.x, ct.y + a0.y, ct.z + a0.z, ct.w + a0.w);
+                        brow[cur * CQ] = make_float4(cbm.x + a2.x, cbm.y + a2.y, cbm.z + a2.z, cbm.w + a2.w);
                         ct = a1; cbm = a3;
-                        a0 = a1 = a2 = a3 = 0.f;
+                        a0 = a1 = a2 = a3 = zero4();
                         ++cur;
                         nb = cbr[cur + 1];
                     }
-                    a0 = fmaf(k[u].x, g[u], a0); a1 = fmaf(k[u].y, g[u], a1);
-                    a2 = fmaf(k[u].z, g[u], a2); a3 = fmaf(k[u].w, g[u], a3);
+                    a0 = fma4(k[u].x, g[u], a0); a1 = fma4(k[u].y, g[u], a1);
+                    a2 = fma4(k[u].z, g[u], a2); a3 = fma4(k[u].w, g[u], a3);
                     if (TWO) {
-                        a0 = fmaf(k2[u].x, h[u], a0); a1 = fmaf(k2[u].y, h[u], a1);
-                        a2 = fmaf(k2[u].z, h[u], a2); a3 = fmaf(k2[u].w, h[u], a3);
+                        a0 = fma4(k2[u].x, h[u], a0); a1 = fma4(k2[u].y, h[u], a1);
+                        a2 = fma4(k2[u].z, h[u], a2); a3 = fma4(k2[u].w, h[u], a3);
                     }
                 }
             }
         }
-        while (cur < TX) {
-            trow[cur * NS] = ct + a0;
-            brow[cur * NS] = cbm + a2;
+        while (cur < SEGW) {
+            trow[cur * CQ] = make_float4(ct.x + a0.x, ct.y + a0.y, ct.z + a0.z, ct.w + a0.w);
+            brow[cur * CQ] = make_float4(cbm.x + a2.x, cbm.y + a2.y, cbm.z + a2.z, cbm.w + a2.w);
             ct = a1; cbm = a3;
-            a0 = a1 = a2 = a3 = 0.f;
+            a0 = a1 = a2 = a3 = zero4();
             ++cur;
         }
-        trow[TX * NS] = ct;
-        brow[TX * NS] = cbm;
+        trow[SEGW * CQ] = ct;
+        brow[SEGW * CQ] = cbm;
     }
     __syncthreads();
 
-    // node (ly, lx) of the tile = global node (ty*TY + ly - 1, tx*TX + lx - 1); its sum is
-    // top[ly][lx] (cell row ly, low-y nodes) + bot[ly-1][lx] (cell row ly-1, high-y nodes)
+    // node (ly, lx) of the tile = global node (ty*TY + ly - 1, tx*TX + lx - 1).  Column lx is slot
+    // lx % SEGW of run lx / SEGW and, when lx is a run boundary, also the last slot of the run before.
     const int W = d.size[0], H = d.size[1];
+    const float *topf = reinterpret_cast<const float *>(top), *botf = reinterpret_cast<const float *>(bot);
     float *gi = grad_input + (int64_t)n * C * d.vol;
     for (int idx = threadIdx.x; idx < C * (TY + 1) * (TX + 1); idx += 256) {
         int lx = idx % (TX + 1);
         int rest = idx / (TX + 1);
-        int ly = rest % (TY + 1);
+        int lyy = rest % (TY + 1);
         int ch = rest / (TY + 1);
-        int gx = tx * TX + lx - 1, gy = ty * TY + ly - 1;
+        int gx = tx * TX + lx - 1, gy = ty * TY + lyy - 1;
         if (gx < 0 || gx >= W || gy < 0 || gy >= H) continue;
+        int sg = lx / SEGW, sl = lx - sg * SEGW;
         float v = 0.f;
-        if (ly < TY) v += top[(ly * (TX + 1) + lx) * NS + ch];
-        if (ly > 0) v += bot[((ly - 1) * (TX + 1) + lx) * NS + ch];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {          // side 0: this run's slot; side 1: previous run's end slot
+            int s2 = side ? sg - 1 : sg, l2 = side ? SEGW : sl;
+            if (side && sl != 0) continue;
+            if (s2 < 0 || s2 >= NSEG) continue;
+            if (lyy < TY) v += topf[((lyy * NSEG + s2) * (SEGW + 1) + l2) * C + ch];
+            if (lyy > 0) v += botf[(((lyy - 1) * NSEG + s2) * (SEGW + 1) + l2) * C + ch];
+        }
         if (v != 0.f) unsafeAtomicAdd(gi + (int64_t)ch * d.vol + (int64_t)gy * W + gx, v);
     }
 }

@@ -40,9 +40,9 @@ def test_loader_binds_and_reports_errors_without_gpu():
     # headline config: the tiled path wants scratch for the channels-last copy (64 MiB) in forward ...
     assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 16 * 256 * 256 * 4
     assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
-    # ... payload rows + coefficient records in backward (plus the plan unless one is passed in)
+    # ... one fat row (C payload floats + 4 coefficients) per sample in backward (plus the plan unless one is passed in)
     S = 16 << 20
-    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 64 + S * 16
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 80
     assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == (
         S * 80 + lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20))
     # shapes outside the fast path (3D, odd channel counts, tiny sample counts) need none

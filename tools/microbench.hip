@@ -241,6 +241,58 @@ void run_rows(float4 *buf, const uint32_t *perm, int64_t rows, float *dout, hipE
            R * 16, ms_w, rows * R * 16.0 / ms_w * 1e-6, ms_r, rows * R * 16.0 / ms_r * 1e-6);
 }
 
+// MB8: walker-style gather of fat rows: 16 lanes = one walker, reads for each of its rows 16 floats
+// (one per lane) + NCOEF float4 coefficient records broadcast; rows visited in `perm` order.
+// STRIDE = floats between rows.
+template <int STRIDE, int NPAY, int NCOEF>
+__global__ __launch_bounds__(256) void walker_gather(const float *fat, const uint32_t *perm, int64_t rows, float *out) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 4, c = threadIdx.x & 15;
+    const int64_t per = 256;                       // rows per walker
+    int64_t j0 = (int64_t)w * per;
+    if (j0 >= rows) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t j = j0; j < j0 + per; j += 4) {
+        uint32_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = perm[j + u];
+        float g[4][NPAY];
+        float4 k[4][NCOEF];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *row = fat + (int64_t)r[u] * STRIDE;
+#pragma unroll
+            for (int q = 0; q < NPAY; ++q) g[u][q] = row[16 * q + c];
+#pragma unroll
+            for (int q = 0; q < NCOEF; ++q) k[u][q] = *reinterpret_cast<const float4 *>(row + 16 * NPAY + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < NPAY; ++q) {
+                float4 kk = k[u][q < NCOEF ? q : 0];
+                a0 = fmaf(kk.x, g[u][q], a0); a1 = fmaf(kk.y, g[u][q], a1);
+                a2 = fmaf(kk.z, g[u][q], a2); a3 = fmaf(kk.w, g[u][q], a3);
+            }
+    }
+    if (a0 + a1 + a2 + a3 == -12345.f) out[0] = a0;
+}
+template <int STRIDE, int NPAY, int NCOEF>
+void run_walker(const float *buf, const uint32_t *perm, int64_t rows, float *dout, hipEvent_t e0, hipEvent_t e1, const char *what) {
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        walker_gather<STRIDE, NPAY, NCOEF><<<(unsigned)(rows / 256 * 16 / 256), 256>>>(buf, perm, rows, dout);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("MB8 walker gather %-34s stride %3d B, useful %3d B/row: %.3f ms (%.0f GB/s useful)\n", what, STRIDE * 4,
+           (16 * NPAY + 4 * NCOEF) * 4, ms, rows * (16.0 * NPAY + 4 * NCOEF) * 4 / ms * 1e-6);
+}
+__global__ void make_ident(uint32_t *perm, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) perm[i] = (uint32_t)i;
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main() {
@@ -352,6 +404,20 @@ int main() {
         run_rows<8>(buf, perm, rows, dout, e0, e1);
         run_rows<10>(buf, perm, rows, dout, e0, e1);
         run_rows<12>(buf, perm, rows, dout, e0, e1);
+        CK(hipFree(buf));
+        CK(hipMalloc(&buf, rows * 256));
+        CK(hipMemset(buf, 0, rows * 256));
+        make_perm<<<rows / 256, 256>>>(perm, rows, (uint32_t)(rows - 1), 2654435761u);
+        run_walker<16, 1, 0>((float *)buf, perm, rows, dout, e0, e1, "random, G only");
+        run_walker<20, 1, 1>((float *)buf, perm, rows, dout, e0, e1, "random, G+coef packed");
+        run_walker<32, 1, 1>((float *)buf, perm, rows, dout, e0, e1, "random, G+coef in a 128 B line");
+        run_walker<40, 2, 2>((float *)buf, perm, rows, dout, e0, e1, "random, 2 payloads + 2 coef packed");
+        run_walker<48, 2, 2>((float *)buf, perm, rows, dout, e0, e1, "random, 2+2 stride 192");
+        run_walker<64, 2, 2>((float *)buf, perm, rows, dout, e0, e1, "random, 2+2 in 256 B");
+        make_ident<<<rows / 256, 256>>>(perm, rows);
+        run_walker<16, 1, 0>((float *)buf, perm, rows, dout, e0, e1, "sequential, G only");
+        run_walker<20, 1, 1>((float *)buf, perm, rows, dout, e0, e1, "sequential, G+coef packed");
+        run_walker<40, 2, 2>((float *)buf, perm, rows, dout, e0, e1, "sequential, 2+2 packed");
         for (int rep = 0; rep < 2; ++rep) { CK(hipEventRecord(e0)); quad_gather_v<1><<<rows * 4 / 256, 256>>>(buf, 65536, 256, 16, rows, dout); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }
         printf("MB6b quad gather, x even (pairs share a 128 B line): %.3f ms\n", time_ms(e0, e1));
         for (int rep = 0; rep < 2; ++rep) { CK(hipEventRecord(e0)); quad_gather_v<2><<<rows * 4 / 256, 256>>>(buf, 65536, 256, 16, rows, dout); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); }

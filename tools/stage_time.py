@@ -8,7 +8,8 @@ from cosinesampler_amd import multicell_offset, ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda", 0)
-N, C, H, P = 16, 16, 256, 1 << 20
+N, C, H, P = 16, 16, int(sys.argv[2]) if len(sys.argv) > 2 else 256, 1 << 20
+print("H=W=%d" % H)
 torch.manual_seed(0)
 cells = torch.rand(N, C, H, H, device=dev)
 xy = torch.rand(P, 2, device=dev) * 2 - 1
