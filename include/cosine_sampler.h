@@ -34,7 +34,8 @@
  *     for it).  Problems outside the fast path (3D, C not in {4,8,16}, tiny S) ignore both.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
- *   - Thread-safe and re-entrant: the library keeps no mutable global state.
+ *   - Thread-safe and re-entrant: the library keeps no mutable global state (the one exception is
+ *     the process-wide testing knob cs_debug_force_path).
  */
 #ifndef COSINE_SAMPLER_H
 #define COSINE_SAMPLER_H
@@ -69,9 +70,10 @@ size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
                   int64_t W, void *stream);
 
-/* Point-binning plan of one grid (2D fast path): tile-sorted slot of every sample + the cell-sorted
- * visiting order inside every 16x16-cell tile.  Depends on grid, offset, N, H, W, P and the three
- * flags, not on C or the blending kernel.  cs2d_plan_bytes returns 0 when the fast path does not apply. */
+/* Point-binning plan of one grid (2D fast path): the sample ids sorted by (n, 16x16-cell tile, cell)
+ * with the first position of every tile and of every cell.  Depends on grid, offset, N, H, W, P and
+ * the three flags, not on the blending kernel (C only decides whether the fast path applies).
+ * cs2d_plan_bytes returns 0 when the fast path does not apply. */
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P);
 int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
