@@ -75,7 +75,7 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
 
     P = 1 << 12
     t = run(P)                     # warm-up + calibration
-    while t < seconds_budget / 8 and P < (1 << 18):
+    while t < seconds_budget / 4 and P < (1 << 20):   # grow the sample until one pass takes ~5 s or more
         P *= 2
         t = run(P)
     t = min(t, run(P))
@@ -185,6 +185,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     total_bytes = sum(ab.values())
 
+    # HBM-side bytes of each stage from the PMC passes of tools/profile_round.sh (same command, same
+    # config), folded by tools/pmc_to_traffic.py; null when this exact config has not been profiled
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "stage_traffic.json")
+    if P == (1 << 20) and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom)
+        except (ValueError, KeyError):
+            traffic = None
+
     if rank == 0:
         line = {
             "metric": "Msamples/s fwd+3xbwd (2D cosine, C=16, 256^2 grid)",
@@ -204,7 +214,7 @@ def main():
                                    % (P, " + 1 RCCL all-reduce of grad_input (64 MiB)" if world > 1 else ""),
                        "samples_per_step_per_gpu": S, "sharding": "points (P) across ranks"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]},
             "pipeline_roofline_frac": total_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
             "stages_ms": stage_ms,

@@ -54,11 +54,14 @@ __device__ __forceinline__ void kern_eval(float t, float &k0, float &k1, float &
     }
 }
 
-// Coordinate arithmetic is compiled WITHOUT fused multiply-add contraction: t = frac(i) inherits
-// the absolute rounding error of i (one ulp of a coordinate ~ size), and k'(t), k''(t) amplify
-// it, so a contracted and an uncontracted evaluation of the same formula differ by ~1e-5
-// relative at H=W=256.  Evaluated operation by operation -- like the CPU oracle and like
-// torch.nn.functional.grid_sample's own unnormalize -- the source index is bit-reproducible.
+// Coordinate arithmetic is pinned operation by operation: t = frac(i) inherits the absolute
+// rounding error of i (one ulp of a coordinate ~ size) and k'(t), k''(t) amplify it, so two
+// evaluations of the same formula that differ only in where the compiler fused a multiply-add
+// differ by ~1e-5 relative at H=W=256.  Compiler contraction is therefore OFF here and the two
+// multiply-adds a GPU build of the reference performs (nvcc/hipcc fuse `x*(size-1) + offset` and
+// `(g+1)*size - 1`, as does the HIP build of torch's grid_sampler_unnormalize) are written as
+// explicit fmaf -- in this file and in oracle/cs_oracle.c alike -- so the source index is
+// bit-identical to the CPU oracle's and to torch.nn.functional.grid_sample's.
 __device__ __forceinline__ float clip_coord(float in, int limit, float &g) {  // 2d.cu:99-116
 #pragma clang fp contract(off)
     if (in <= 0.0f) { g = 0.0f; return 0.0f; }
@@ -91,10 +94,10 @@ __device__ __forceinline__ float source_index(float g, int size, int pad, int al
     if (align) {
         int s = multicell ? size - 1 : size;            // 2d.cu:57-59
         mu = (float)(s - 1) * 0.5f;                     // 2d.cu:80
-        c = ((g + 1.0f) * 0.5f) * (float)(s - 1) + off; // 2d.cu:61
+        c = fmaf((g + 1.0f) * 0.5f, (float)(s - 1), off); // 2d.cu:61
     } else {
         mu = (float)size * 0.5f;                        // 2d.cu:84
-        c = (((g + 1.0f) * (float)size - 1.0f) * 0.5f) + off;
+        c = fmaf(g + 1.0f, (float)size, -1.0f) * 0.5f + off;   // 2d.cu:64
     }
     if (pad == PAD_BORDER) {
         float gc;

@@ -68,10 +68,12 @@ static float unnormalize(float g, int64_t size, int align, float off, int multic
     if (align) {
         if (multicell) size = size - 1;          /* 2d.cu:57-59, :77-79 */
         *mult = (float)(size - 1) / 2;           /* 2d.cu:80 */
-        return ((g + 1) / 2) * (size - 1) + off; /* 2d.cu:61, :81 */
+        /* a GPU build fuses this multiply-add (nvcc fmad / hipcc contraction); made explicit so
+         * that the checker and the kernels agree bit for bit on the source index */
+        return fmaf((g + 1) / 2, (float)(size - 1), off); /* 2d.cu:61, :81 */
     }
     *mult = (float)size / 2;                     /* 2d.cu:84 */
-    return (((g + 1) * size - 1) / 2) + off;     /* 2d.cu:64, :85 */
+    return fmaf(g + 1, (float)size, -1.0f) / 2 + off; /* 2d.cu:64, :85 */
 }
 
 static float clip_grad(float in, int64_t limit, float *g) { /* 2d.cu:99-116 */
