@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
     constexpr int SEGW = CQ;                   // cells per walker
     constexpr int NSEG = TX / SEGW;            // walkers per cell row
     constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
-    constexpr int U = 4;                       // samples in flight per walker
+    constexpr int U = TWO ? 4 : 8;             // samples in flight per walker
     static_assert(TY * NSEG * CQ == 256, "one workgroup = all walkers of a tile");
     __shared__ float4 top[TY * NODES * CQ];    // sums for the nodes on the low-y side of each cell row
     __shared__ float4 bot[TY * NODES * CQ];    // ... on the high-y side
@@ -669,11 +669,15 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
         const uint32_t j1 = cbr[SEGW];
         uint32_t nb = cbr[1];                   // first position of the next cell
         const uint32_t *sorted = pl.sorted + b0;
-        for (uint32_t j = cbr[0]; j < j1; j += U) {
+        const uint32_t jbeg = cbr[0];
+        uint32_t ids[U];                        // sample ids of the NEXT batch: fetched one batch ahead so that
+#pragma unroll                                  // the row fetches never wait on the id fetch
+        for (int u = 0; u < U; ++u) ids[u] = jbeg < j1 ? sorted[min(jbeg + u, j1 - 1)] : 0u;
+        for (uint32_t j = jbeg; j < j1; j += U) {
             float4 g[U], k[U], h[U], k2[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {       // all loads of the batch first
-                const float *row = fat + (int64_t)sorted[min(j + u, j1 - 1)] * STRIDE;
+            for (int u = 0; u < U; ++u) {       // all row loads of the batch first
+                const float *row = fat + (int64_t)ids[u] * STRIDE;
                 g[u] = *reinterpret_cast<const float4 *>(row + 4 * q);
                 if (TWO) {
                     h[u] = *reinterpret_cast<const float4 *>(row + C + 4 * q);
@@ -682,6 +686,10 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
                 } else {
                     k[u] = *reinterpret_cast<const float4 *>(row + C);
                 }
+            }
+            if (j + U < j1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ids[u] = sorted[min(j + U + u, j1 - 1)];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
