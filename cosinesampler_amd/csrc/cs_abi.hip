@@ -143,13 +143,14 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
     if (ntx * nty > 12288) return false;                 // tile histogram lives in LDS (48 KiB)
     if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
     if (N > 65535 || H * W * C >= ((int64_t)1 << 31)) return false;   // gridDim.y = N; 32-bit node offsets
+    if (P > ((int64_t)1 << 24)) return false;                          // plan keys pack (p << 8) | cell
     if (mode == 2) return true;
     return S >= kTiledMinSamples;
 }
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks;
-    size_t off_sorted, off_sid, off_cell1, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
+    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
 };
 
 PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
@@ -161,8 +162,7 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     int64_t S = N * P;
     size_t o = 0;
     L.off_sorted = o;     o += align256((size_t)S * 4);
-    L.off_sid = o;        o += align256((size_t)S * 4);
-    L.off_cell1 = o;      o += align256((size_t)S);
+    L.off_key = o;        o += align256((size_t)S * 4);
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
     L.off_cell_begin = o; o += align256((size_t)N * L.ntiles * (tl::CELLS + 1) * 4);
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
@@ -175,8 +175,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     char *b = (char *)blob;
     tl::Plan p;
     p.sorted = (uint32_t *)(b + L.off_sorted);
-    p.sid = (uint32_t *)(b + L.off_sid);
-    p.cell1 = (uint8_t *)(b + L.off_cell1);
+    p.key = (uint32_t *)(b + L.off_key);
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
     p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
@@ -198,7 +197,7 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
     tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
     tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
     tl::plan_scatter<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
-    tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl);
+    tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl, pb.d.P);
     return launch_status();
 }
 

@@ -35,14 +35,13 @@ namespace tiled {
 
 constexpr int TX = 16, TY = 16;            // cells per tile
 constexpr int CELLS = TX * TY;             // 256 -> local cell id fits a byte
-constexpr int CHUNK = 4096;                // samples per plan workgroup
+constexpr int CHUNK = 16384;               // samples per plan workgroup
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
 struct Plan {
     uint32_t *sorted;      // [S]  sorted position (by n, tile, cell) -> sample id n*P+p; only the first
                            //      tile_begin[N*ntiles] entries are defined (samples touching no node are dropped)
-    uint32_t *sid;         // [S]  scratch: tile-sorted slot -> sample id
-    uint8_t *cell1;        // [S]  scratch: tile-sorted slot -> local cell id
+    uint32_t *key;         // [S]  scratch: tile-sorted slot -> (p << 8) | local cell id   (needs P <= 2^24)
     uint32_t *tile_begin;  // [N*ntiles + 1]      first sorted position of every tile bucket
     uint32_t *cell_begin;  // [N*ntiles*(CELLS+1)] bucket-relative first position of every cell of every tile
     uint32_t *block_hist;  // [N*chunks*ntiles] scratch
@@ -179,15 +178,14 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
             Geo2 q = locate(g.x, g.y, d, f, off, pl.ntx);
             if (q.valid) {
                 uint32_t r = atomicAdd(&cursor[q.tile], 1u);
-                pl.cell1[r] = (uint8_t)q.cell;
-                pl.sid[r] = (uint32_t)s;
+                pl.key[r] = ((uint32_t)p << 8) | (uint32_t)q.cell;   // one scattered word per sample
             }
         }
     }
 }
 
 // one workgroup per (n, tile): counting sort of the bucket by local cell id -> final order
-__global__ __launch_bounds__(256) void plan_tile_sort(Plan pl) {
+__global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     __shared__ uint32_t cnt[CELLS];
     __shared__ uint32_t scan[CELLS];
     const int64_t t = blockIdx.x;
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl) {
     uint32_t *cbeg = pl.cell_begin + t * (CELLS + 1);
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) atomicAdd(&cnt[pl.cell1[j]], 1u);
+    for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) atomicAdd(&cnt[pl.key[j] & 0xFFu], 1u);
     __syncthreads();
     uint32_t v = cnt[threadIdx.x];
     scan[threadIdx.x] = v;
@@ -211,9 +209,11 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl) {
     cbeg[threadIdx.x] = start;
     if (threadIdx.x == CELLS - 1) cbeg[CELLS] = b1 - b0;
     __syncthreads();
+    const uint32_t sbase = (uint32_t)(t / pl.ntiles) * (uint32_t)P;   // n * P
     for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) {
-        uint32_t pos = atomicAdd(&cnt[pl.cell1[j]], 1u);
-        pl.sorted[b0 + pos] = pl.sid[j];
+        uint32_t k = pl.key[j];
+        uint32_t pos = atomicAdd(&cnt[k & 0xFFu], 1u);
+        pl.sorted[b0 + pos] = sbase + (k >> 8);
     }
 }
 
