@@ -106,6 +106,7 @@ int run_backward(const Problem &pb, const float *gOut, const float *input, const
 template <int DIM>
 int run_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
            const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut) {
+    // gInput == nullptr: p-ordered outputs only (the caller scatters separately)
     int rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (pb.d.S == 0) return CS_OK;
@@ -123,6 +124,45 @@ int run_bbb(const Problem &pb, const float *input, const float *grid, const floa
     if (pb.d.S == 0 || pb.d.C == 0) return CS_OK;
     CS_DISPATCH_KERNEL(pb.kernel, (cs::direct_bbb_fused<DIM, KERNEL><<<pb.blocks, kBlock, 0, pb.stream>>>(
                                       input, grid, gOut, cG, hG, hO, offset, gInput, ggOut, pb.d, pb.f)));
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-atomic scatter (any dim, C a power of two <= 64): p-ordered outputs by the direct kernels with
+// their scatter switched off, input-shaped gradient by row_scatter into a channels-last scratch
+// ------------------------------------------------------------------------------------------------
+int log2_exact(int64_t C) {
+    for (int l = 0; l <= 6; ++l)
+        if (C == ((int64_t)1 << l)) return l;
+    return -1;
+}
+
+bool rows_applies(int64_t N, int64_t C, int64_t P, int64_t vol) {
+    int mode = g_force_path.load(std::memory_order_relaxed);
+    if (mode == 1) return false;
+    if (log2_exact(C) < 1) return false;                       // C = 1: rows are single floats, nothing to gain
+    if (N * P * C >= ((int64_t)1 << 40) || vol * C >= ((int64_t)1 << 31)) return false;
+    if (mode == 2) return true;
+    return N * P >= (1 << 16);
+}
+
+template <int DIM, int MODE>
+int run_row_scatter(const Problem &pb, const float *grid, const float *offset, const float *gOut, const float *cG,
+                    const float *hG, const float *hO, float *out_grad, void *workspace, size_t workspace_bytes) {
+    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
+    if (!workspace || workspace_bytes < (size_t)T * 4) return CS_ERR_WORKSPACE;
+    float *acc = (float *)workspace;
+    int rc = zero_async(acc, T, pb.stream);
+    if (rc) return rc;
+    const int logC = log2_exact(pb.d.C);
+    const int64_t lanes = pb.d.S << logC;
+    const unsigned nb = (unsigned)((lanes + kBlock - 1) / kBlock);
+    CS_DISPATCH_KERNEL(pb.kernel, (cs::row_scatter<DIM, KERNEL, MODE><<<nb, kBlock, 0, pb.stream>>>(
+                                      grid, offset, gOut, cG, hG, hO, acc, pb.d, pb.f, logC)));
+    rc = launch_status();
+    if (rc) return rc;
+    dim3 g((unsigned)((pb.d.vol + 63) / 64), (unsigned)pb.d.N);
+    cs::unpack_channels_last<<<g, 256, (size_t)64 * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
     return launch_status();
 }
 
@@ -392,10 +432,11 @@ void cs_debug_force_path(int mode) { g_force_path.store(mode, std::memory_order_
 
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI) {
-    (void)D;
-    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
-    if (!tiled_applies(dim, N, C, H, W, P)) return 0;
-    return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
+    if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
+    const int64_t vol = (dim == 3 ? D : 1) * H * W;
+    if (stage != CS_STAGE_FORWARD && rows_applies(N, C, P, vol)) return align256((size_t)N * C * vol * 4);
+    return 0;
 }
 
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
@@ -438,7 +479,8 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
-    (void)tiled; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;
+    const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \
+    (void)tiled; (void)rows; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;
 
 // zero-element tensors legitimately come with null data pointers
 #define CS_NEED(...)                                                            \
@@ -463,6 +505,12 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                               workspace_bytes);
+    if (rows && grad_input) {
+        int rc = run_backward<2>(pb, grad_output, input, grid, offset, nullptr, grad_grid);
+        if (rc) return rc;
+        return run_row_scatter<2, 0>(pb, grid, offset, grad_output, nullptr, nullptr, nullptr, grad_input, workspace,
+                                     workspace_bytes);
+    }
     return run_backward<2>(pb, grad_output, input, grid, offset, grad_input, grad_grid);
 }
 
@@ -477,6 +525,13 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     if (tiled)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (rows) {
+        int rc = run_bb<2>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, nullptr, grad_grid,
+                           grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<2, 1>(pb, grid, offset, grad_output, grad_out_grid, nullptr, nullptr, grad_input,
+                                     workspace, workspace_bytes);
+    }
     return run_bb<2>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                      grad_grad_out);
 }
@@ -492,6 +547,13 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (rows) {
+        int rc = run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
+                            grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<2, 2>(pb, grid, offset, grad_output, grad_out_grid, grad_out_ggrid, nullptr, grad_input,
+                                     workspace, workspace_bytes);
+    }
     return run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                       grad_grad_out);
 }
@@ -506,6 +568,13 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (rows) {
+        int rc = run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                            nullptr, grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<2, 2>(pb, grid, offset, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout,
+                                     grad_input, workspace, workspace_bytes);
+    }
     return run_bbb<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                       grad_input, grad_grad_out);
 }
@@ -526,6 +595,12 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
                   const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    if (rows && grad_input) {
+        int rc = run_backward<3>(pb, grad_output, input, grid, offset, nullptr, grad_grid);
+        if (rc) return rc;
+        return run_row_scatter<3, 0>(pb, grid, offset, grad_output, nullptr, nullptr, nullptr, grad_input, workspace,
+                                     workspace_bytes);
+    }
     return run_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid);
 }
 
@@ -537,6 +612,13 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
+    if (rows) {
+        int rc = run_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, nullptr, grad_grid,
+                           grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<3, 1>(pb, grid, offset, grad_output, grad_out_grid, nullptr, nullptr, grad_input,
+                                     workspace, workspace_bytes);
+    }
     return run_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                      grad_grad_out);
 }
@@ -549,6 +631,13 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
                                     void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    if (rows) {
+        int rc = run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
+                            grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<3, 2>(pb, grid, offset, grad_output, grad_out_grid, grad_out_ggrid, nullptr, grad_input,
+                                     workspace, workspace_bytes);
+    }
     return run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                       grad_grad_out);
 }
@@ -560,6 +649,13 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    if (rows) {
+        int rc = run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                            nullptr, grad_grad_out);
+        if (rc) return rc;
+        return run_row_scatter<3, 2>(pb, grid, offset, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout,
+                                     grad_input, workspace, workspace_bytes);
+    }
     return run_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                       grad_input, grad_grad_out);
 }

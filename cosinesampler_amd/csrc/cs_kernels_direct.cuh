@@ -38,7 +38,11 @@ struct Sample {
     template <int KERNEL, int ORDER>
     __device__ __forceinline__ bool load(const float *grid, const float *offset, const Dims &d, const Flags &f,
                                          int align) {
-        int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        return load_at<KERNEL, ORDER>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, grid, offset, d, f, align);
+    }
+    template <int KERNEL, int ORDER>
+    __device__ __forceinline__ bool load_at(int64_t s, const float *grid, const float *offset, const Dims &d,
+                                            const Flags &f, int align) {
         if (s >= d.S) return false;
         n = (int)(s / d.P);
         p = s - (int64_t)n * d.P;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
 
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
     const float *ci = cI ? cI + (int64_t)sm.n * d.C * d.vol : nullptr;
-    float *gi = gInput + (int64_t)sm.n * d.C * d.vol;
+    float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
     const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
     float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     for (int c = 0; c < d.C; ++c) {
@@ -274,11 +278,13 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
             for (int a = 0; a < NC; ++a) t = fmaf(v[a], Sg[j][a], t);
             acc[j] = fmaf(t, g, acc[j]);
         }
+        if (gInput) {
 #pragma unroll
-        for (int a = 0; a < NC; ++a)
-            if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], g * Dm[a]);
+            for (int a = 0; a < NC; ++a)
+                if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], g * Dm[a]);
+            gi += d.vol;
+        }
         in += d.vol;
-        gi += d.vol;
         go += d.P;
         ggo += d.P;
     }
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
         Em[a] = esum;
     }
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
-    float *gi = gInput + (int64_t)sm.n * d.C * d.vol;
+    float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
     const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
     const float *ho = hO ? hO + (int64_t)sm.n * d.C * d.P + sm.p : nullptr;
     float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
@@ -335,14 +341,85 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fmaf(v[a], Em[a], o);
         *ggo = o;
+        if (gInput) {
 #pragma unroll
-        for (int a = 0; a < NC; ++a)
-            if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], fmaf(g, Em[a], h * Dm[a]));
+            for (int a = 0; a < NC; ++a)
+                if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], fmaf(g, Em[a], h * Dm[a]));
+            gi += d.vol;
+        }
         in += d.vol;
-        gi += d.vol;
         go += d.P;
         ggo += d.P;
         if (ho) ho += d.P;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Row-atomic scatter for shapes outside the tiled path (3D; 2D with C = 1,2,32,64): the
+// input-shaped gradient of any backward stage, accumulated into a channels-last scratch
+// (N,spatial...,C).  C lanes share a sample, so one wave instruction adds 64/C whole C-float node
+// rows: the memory side retires ~20 G atomic REQUESTS/s whether a request is one float or a
+// contiguous row (tools/microbench.hip MB4), i.e. C times fewer requests than lane-per-sample.
+//   MODE 0: W_a * gOut                 (backward,           2d.cu:469-472 / 3d.cu:507-522)
+//   MODE 1: D_a * gOut                 (backward_backward,  2d.cu:709     / 3d.cu:858-860)
+//   MODE 2: E_a * gOut + D_a * hO      (third backward,     2d.cu:885 / 3d.cu:1063 + modules_2d.py:109-111)
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL, int MODE>
+__global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ grid, const float *__restrict__ offset,
+                                                   const float *__restrict__ gOut, const float *__restrict__ cG,
+                                                   const float *__restrict__ hG, const float *__restrict__ hO,
+                                                   float *__restrict__ acc_cl, Dims d, Flags f, int logC) {
+    constexpr int NC = 1 << DIM;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t & ((1 << logC) - 1));
+    Sample<DIM> sm;
+    if (!sm.template load_at<KERNEL, (MODE == 0 ? 0 : (MODE == 1 ? 1 : 2))>(t >> logC, grid, offset, d, f, f.align)) return;
+    const int64_t so = ((int64_t)sm.n * d.P + sm.p) * DIM;
+    float cg[DIM], hg[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        cg[j] = (MODE >= 1 && cG) ? cG[so + j] : 0.0f;
+        hg[j] = (MODE == 2 && hG) ? hG[so + j] : 0.0f;
+    }
+    const float g = gOut[((int64_t)sm.n * d.C + c) * d.P + sm.p];
+    const float h = (MODE == 2 && hO) ? hO[((int64_t)sm.n * d.C + c) * d.P + sm.p] : 0.0f;
+    float *dst = acc_cl + (int64_t)sm.n * d.vol * d.C + c;
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        if (sm.node[a] < 0) continue;
+        float v;
+        if (MODE == 0) {
+            float w = sm.ax[0].w[a & 1];
+#pragma unroll
+            for (int j = 1; j < DIM; ++j) w *= sm.ax[j].w[(a >> j) & 1];
+            v = w * g;
+        } else {
+            float dsum = 0.0f, esum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                dsum = fmaf(sm.first(a, j), cg[j], dsum);
+                if (MODE == 2) esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+            }
+            v = MODE == 1 ? g * dsum : fmaf(g, esum, h * dsum);
+        }
+        unsafeAtomicAdd(dst + sm.node[a] * d.C, v);
+    }
+}
+
+// channels-last scratch (N,vol,C) -> caller's (N,C,vol); any C <= 64
+__global__ __launch_bounds__(256) void unpack_channels_last(const float *__restrict__ in, float *__restrict__ out,
+                                                            int C, int64_t vol) {
+    extern __shared__ float tile[];  // [64][C+1]
+    const int n = blockIdx.y;
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < C * 64; idx += 256) {
+        int v = idx / C, c = idx - v * C;
+        tile[v * (C + 1) + c] = (v0 + v < vol) ? in[((int64_t)n * vol + v0 + v) * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * 64; idx += 256) {
+        int c = idx >> 6, v = idx & 63;
+        if (v0 + v < vol) out[((int64_t)n * C + c) * vol + v0 + v] = tile[v * (C + 1) + c];
     }
 }
 

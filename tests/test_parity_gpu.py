@@ -123,6 +123,29 @@ def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
                      % (C, ke, pad, align, mc, shared, k))
 
 
+ROW_CASES = [(3, 8, 0, 0, True, True), (3, 8, 2, 0, True, True), (3, 2, 1, 1, False, False), (3, 16, 2, 2, True, False),
+             (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False)]
+
+
+@pytest.mark.parametrize("d,C,ke,pad,align,mc", ROW_CASES)
+def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc):
+    """Shapes outside the tiled path (3D; 2D with C = 2, 32, 64): p-ordered outputs from the direct
+    kernels, input-shaped gradients by row-atomic scatter into a channels-last scratch.  Forced on."""
+    N, P = 2, 1500
+    sp = (11, 13) if d == 2 else (6, 9, 7)
+    t = _case(d, N, C, sp, P, seed=8100 + 10 * C + ke, spread=1.2)
+    off = offsets(N, mc)
+    want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
+    ops.force_path(2)
+    try:
+        got = _run_all_stages(ops, t, off, pad, align, ke, mc, DEV)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for k in want:
+        assert_close(got[k], want[k], "rows d=%d C=%d kernel=%d pad=%d align=%s mc=%s: %s" % (d, C, ke, pad, align, mc, k))
+
+
 def test_tiled_path_empty_and_clustered_points():
     """Degenerate point sets for the plan: every point in one cell, every point out of range."""
     N, C, sp = 2, 16, (40, 33)

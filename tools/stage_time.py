@@ -40,6 +40,31 @@ for name, fn in stages.items():
     e1.record()
     torch.cuda.synchronize()
     print("%-28s %8.3f ms" % (name, e0.elapsed_time(e1) / reps), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "3d":
+    # BASELINE.json configs[3]: 3D smoothstep N=8 C=8 128^3 P=2^19
+    N3, C3, S3, P3 = 8, 8, 128, 1 << 19
+    c3 = torch.rand(N3, C3, S3, S3, S3, device=dev)
+    g3 = torch.rand(N3, 1, 1, P3, 3, device=dev) * 2 - 1
+    go3 = torch.randn(N3, C3, 1, 1, P3, device=dev); ho3 = torch.randn_like(go3)
+    cg3 = torch.randn_like(g3); hg3 = torch.randn_like(g3)
+    o3 = multicell_offset(N3, True, dev)
+    st3 = {
+        "3D forward": lambda: ops.forward(c3, g3, o3, 0, True, 2, True),
+        "3D backward": lambda: ops.backward(go3, c3, g3, o3, 0, True, True, 2, True),
+        "3D backward_backward": lambda: ops.backward_backward(None, cg3, c3, g3, go3, o3, 0, True, False, 2, True),
+        "3D bbb_fused": lambda: ops.bbb_fused(c3, g3, go3, cg3, hg3, ho3, o3, 0, True, 2, True),
+    }
+    for name, fn in st3.items():
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("%-28s %8.3f ms" % (name, e0.elapsed_time(e1) / reps), flush=True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
