@@ -25,6 +25,10 @@ struct Dims {
     int64_t P;      // samples per n
     int64_t S;      // N * P
     int64_t vol;    // D*H*W elements of one (n,c) volume
+    // layout of the table the kernels gather `input` from: element (n, c, node) sits at
+    // n*C*vol + node*tab_ns + c*tab_cs  -- (1, vol) for the caller's NC[D]HW tensor, (C, 1) for the
+    // channels-last copy made by pack_channels_last (one node = one contiguous C-float row)
+    int64_t tab_ns, tab_cs;
 };
 
 template <int DIM>
@@ -113,9 +117,10 @@ struct Sample {
 };
 
 template <int DIM>
-__device__ __forceinline__ void gather(const float *vol, const int64_t (&node)[1 << DIM], float (&v)[1 << DIM]) {
+__device__ __forceinline__ void gather(const float *vol, const int64_t (&node)[1 << DIM], float (&v)[1 << DIM],
+                                       int64_t ns = 1) {
 #pragma unroll
-    for (int a = 0; a < (1 << DIM); ++a) v[a] = node[a] >= 0 ? vol[node[a]] : 0.0f;
+    for (int a = 0; a < (1 << DIM); ++a) v[a] = node[a] >= 0 ? vol[node[a] * ns] : 0.0f;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -135,13 +140,13 @@ __global__ __launch_bounds__(256) void direct_forward(const float *__restrict__ 
     float *o = out + (int64_t)sm.n * d.C * d.P + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float v[NC];
-        gather<DIM>(in, sm.node, v);
+        gather<DIM>(in, sm.node, v, d.tab_ns);
         float acc = 0.0f;
 #pragma unroll
         for (int a = 0; a < NC; ++a)
             if (sm.node[a] >= 0) acc = fmaf(v[a], W[a], acc);
         *o = acc;
-        in += d.vol;
+        in += d.tab_cs;
         o += d.P;
     }
 }
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void direct_backward(const float *__restrict__
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
         float v[NC];
-        gather<DIM>(in, sm.node, v);
+        gather<DIM>(in, sm.node, v, d.tab_ns);
         if (gi) {
 #pragma unroll
             for (int a = 0; a < NC; ++a)
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void direct_backward(const float *__restrict__
             for (int a = 0; a < NC; ++a) t = fmaf(v[a], oth[j][a], t);
             acc[j] = fmaf(t, g, acc[j]);
         }
-        in += d.vol;
+        in += d.tab_cs;
         go += d.P;
     }
     float *gg = grad_grid + ((int64_t)sm.n * d.P + sm.p) * DIM;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
         float v[NC];
-        gather<DIM>(in, sm.node, v);
+        gather<DIM>(in, sm.node, v, d.tab_ns);
         float o = 0.0f;
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fmaf(v[a], Dm[a], o);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
                 if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], g * Dm[a]);
             gi += d.vol;
         }
-        in += d.vol;
+        in += d.tab_cs;
         go += d.P;
         ggo += d.P;
     }
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
         float g = *go;
         float h = ho ? *ho : 0.0f;
         float v[NC];
-        gather<DIM>(in, sm.node, v);
+        gather<DIM>(in, sm.node, v, d.tab_ns);
         float o = 0.0f;
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fmaf(v[a], Em[a], o);
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
                 if (sm.node[a] >= 0) unsafeAtomicAdd(gi + sm.node[a], fmaf(g, Em[a], h * Dm[a]));
             gi += d.vol;
         }
-        in += d.vol;
+        in += d.tab_cs;
         go += d.P;
         ggo += d.P;
         if (ho) ho += d.P;

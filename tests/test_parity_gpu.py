@@ -127,8 +127,20 @@ ROW_CASES = [(3, 8, 0, 0, True, True), (3, 8, 2, 0, True, True), (3, 2, 1, 1, Fa
              (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False)]
 
 
+class _Shared(object):
+    """ops with one StepContext threaded through every call (what the autograd chain does)."""
+
+    def __init__(self):
+        self.step = ops.StepContext()
+
+    def __getattr__(self, name):
+        fn = getattr(ops, name)
+        return lambda *a: fn(*a, ctx=self.step)
+
+
 @pytest.mark.parametrize("d,C,ke,pad,align,mc", ROW_CASES)
-def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc):
+@pytest.mark.parametrize("shared", [False, True])
+def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared):
     """Shapes outside the tiled path (3D; 2D with C = 2, 32, 64): p-ordered outputs from the direct
     kernels, input-shaped gradients by row-atomic scatter into a channels-last scratch.  Forced on."""
     N, P = 2, 1500
@@ -138,7 +150,8 @@ def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc):
     want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
     ops.force_path(2)
     try:
-        got = _run_all_stages(ops, t, off, pad, align, ke, mc, DEV)
+        # shared: the channels-last copy of `input` is built once and the direct kernels gather from it
+        got = _run_all_stages(_Shared() if shared else ops, t, off, pad, align, ke, mc, DEV)
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)

@@ -48,11 +48,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "3d":
     go3 = torch.randn(N3, C3, 1, 1, P3, device=dev); ho3 = torch.randn_like(go3)
     cg3 = torch.randn_like(g3); hg3 = torch.randn_like(g3)
     o3 = multicell_offset(N3, True, dev)
+    sc3 = ops.StepContext()
     st3 = {
-        "3D forward": lambda: ops.forward(c3, g3, o3, 0, True, 2, True),
-        "3D backward": lambda: ops.backward(go3, c3, g3, o3, 0, True, True, 2, True),
-        "3D backward_backward": lambda: ops.backward_backward(None, cg3, c3, g3, go3, o3, 0, True, False, 2, True),
-        "3D bbb_fused": lambda: ops.bbb_fused(c3, g3, go3, cg3, hg3, ho3, o3, 0, True, 2, True),
+        "3D forward": lambda: ops.forward(c3, g3, o3, 0, True, 2, True, ctx=sc3),
+        "3D backward": lambda: ops.backward(go3, c3, g3, o3, 0, True, True, 2, True, ctx=sc3),
+        "3D backward_backward": lambda: ops.backward_backward(None, cg3, c3, g3, go3, o3, 0, True, False, 2, True, ctx=sc3),
+        "3D bbb_fused": lambda: ops.bbb_fused(c3, g3, go3, cg3, hg3, ho3, o3, 0, True, 2, True, ctx=sc3),
+        "3D forward (no ctx: NCDHW gathers)": lambda: ops.forward(c3, g3, o3, 0, True, 2, True),
     }
     for name, fn in st3.items():
         for _ in range(2):
