@@ -7,6 +7,7 @@
 
 #include "../../include/cosine_sampler.h"
 #include "cs_kernels_direct.cuh"
+#include "cs_points_cl.cuh"
 #include "cs_tiled.cuh"
 
 namespace {
@@ -149,11 +150,21 @@ bool rows_applies(int64_t N, int64_t C, int64_t P, int64_t vol) {
 }
 
 template <int DIM, int MODE>
+int row_scatter_into(const Problem &pb, const float *grid, const float *offset, const float *gOut, const float *cG,
+                     const float *hG, const float *hO, float *out_grad, float *acc);
+
+template <int DIM, int MODE>
 int run_row_scatter(const Problem &pb, const float *grid, const float *offset, const float *gOut, const float *cG,
                     const float *hG, const float *hO, float *out_grad, void *workspace, size_t workspace_bytes) {
     const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
     if (!workspace || workspace_bytes < (size_t)T * 4) return CS_ERR_WORKSPACE;
-    float *acc = (float *)workspace;
+    return row_scatter_into<DIM, MODE>(pb, grid, offset, gOut, cG, hG, hO, out_grad, (float *)workspace);
+}
+
+template <int DIM, int MODE>
+int row_scatter_into(const Problem &pb, const float *grid, const float *offset, const float *gOut, const float *cG,
+                     const float *hG, const float *hO, float *out_grad, float *acc) {
+    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
     int rc = zero_async(acc, T, pb.stream);
     if (rc) return rc;
     const int logC = log2_exact(pb.d.C);
@@ -408,6 +419,101 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
 }
 
+// ------------------------------------------------------------------------------------------------
+// rows path with channels-last point kernels (3D, C in {4,8,16})
+// ------------------------------------------------------------------------------------------------
+bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
+    return dim == 3 && (C == 4 || C == 8 || C == 16) && rows_applies(N, C, P, vol) && N * P < ((int64_t)1 << 31);
+}
+
+size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_cl, int have_cI) {
+    size_t T = align256((size_t)N * C * vol * 4), need = 0;
+    if (!have_cl) need += T;
+    if (stage == CS_STAGE_FORWARD) return need;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    return need + T;   // + the channels-last accumulator of row_scatter
+}
+
+// resolve the channels-last table (caller's or packed into the workspace)
+int rows_cl_table(const Problem &pb, const float *input, const float *input_cl, Carve &ws, const float *&icl) {
+    if (input_cl) { icl = input_cl; return CS_OK; }
+    float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    icl = buf;
+    return pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+}
+
+template <int DIM>
+int rcl_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
+                const float *input_cl, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    const float *icl;
+    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::forward<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      icl, grid, offset, output, pb.d, pb.f))));
+    return launch_status();
+}
+
+template <int DIM>
+int rcl_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
+                 float *grad_input, float *grad_grid, const float *input_cl, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    const float *icl;
+    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      gOut, icl, grid, offset, grad_grid, pb.d, pb.f))));
+    rc = launch_status();
+    if (rc || !grad_input) return rc;
+    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    return row_scatter_into<DIM, 0>(pb, grid, offset, gOut, nullptr, nullptr, nullptr, grad_input, acc);
+}
+
+template <int DIM>
+int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
+           const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut, const float *input_cl,
+           void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    const float *icl;
+    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    if (cI) {
+        float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        if (rc) return rc;
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                          buf, cG, icl, grid, gOut, offset, gGrid, ggOut, pb.d, pb.f))));
+    } else {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, false><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                          nullptr, cG, icl, grid, gOut, offset, gGrid, ggOut, pb.d, pb.f))));
+    }
+    rc = launch_status();
+    if (rc) return rc;
+    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    return row_scatter_into<DIM, 1>(pb, grid, offset, gOut, cG, nullptr, nullptr, gInput, acc);
+}
+
+template <int DIM>
+int rcl_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
+            const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
+            const float *input_cl, void *workspace, size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    const float *icl;
+    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      icl, grid, cG, hG, offset, ggOut, pb.d, pb.f))));
+    rc = launch_status();
+    if (rc) return rc;
+    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    return row_scatter_into<DIM, 2>(pb, grid, offset, gOut, cG, hG, hO, gInput, acc);
+}
+
 bool any_null(std::initializer_list<const void *> ps) {
     for (const void *p : ps)
         if (!p) return true;
@@ -437,14 +543,16 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
     if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
+    if (rows_cl_applies(dim, N, C, P, vol)) return rows_cl_workspace(stage, N, C, vol, have_input_cl, have_cI);
     if (stage != CS_STAGE_FORWARD && rows_applies(N, C, P, vol)) return align256((size_t)N * C * vol * 4);
     return 0;
 }
 
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
-    if (!tiled_applies(dim, N, C, H, W, P)) return 0;
-    return align256((size_t)N * C * (dim == 3 ? D : 1) * H * W * 4);
+    const int64_t vol = (dim == 3 ? D : 1) * H * W;
+    if (!tiled_applies(dim, N, C, H, W, P) && !rows_cl_applies(dim, N, C, P, vol)) return 0;
+    return align256((size_t)N * C * vol * 4);
 }
 
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
@@ -592,6 +700,8 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
                  void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, offset, output)
+    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+        return rcl_forward<3>(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     return run_forward<3>(pb, table_, grid, offset, output);
 }
 
@@ -601,6 +711,9 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
                   const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+        return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, workspace,
+                               workspace_bytes);
     if (rows && grad_input) {
         int rc = run_backward<3>(pb, grad_output, table_, grid, offset, nullptr, grad_grid);
         if (rc) return rc;
@@ -618,6 +731,9 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
+    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+        return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
+                         grad_grad_out, input_cl, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bb<3>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
@@ -637,6 +753,9 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
                                     void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+        return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
+                          grad_grad_out, input_cl, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -655,6 +774,9 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+        return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                          grad_input, grad_grad_out, input_cl, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);
