@@ -6,11 +6,12 @@ bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, no gfx950 read-side correction applied
 4 B/lane and the gathers are 16 B/lane from scattered lines -- neither is the calibrated 16 B/lane
 coalesced pattern of MI355X_MICROARCH.md, whose FETCH_SIZE reads exactly half the bytes; the true
 read traffic therefore lies between the raw figure and twice it)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
-    for f in glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c)):
+    files = sorted(glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c)), key=os.path.getmtime)
+    for f in files[-1:]:                      # the newest collection only
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {k: {c: {"launches": len(x), "per_launch": x[-1]} for c, x in v.items()} for k, v in agg.items() if "cs::" in k}
