@@ -36,7 +36,6 @@ namespace tiled {
 constexpr int TX = 16, TY = 16;            // cells per tile
 constexpr int CELLS = TX * TY;             // 256 -> local cell id fits a byte
 constexpr int CHUNK = 16384;               // samples per plan workgroup
-constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
 struct Plan {
     uint32_t *sorted;      // [S]  sorted position (by n, tile, cell) -> sample id n*P+p; only the first
@@ -219,12 +218,12 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
 
 // ------------------------------------------------------------------------------------------------
 // point kernels.  Launch: grid (ceil(P/256), N), 256 threads; a wave owns 64 consecutive points of
-// one n.  Two phases per wave:
-//   1. lane = sample: coordinates, weights, derivatives  ->  a small record in LDS;
+// one n.  point_forward works in two phases per wave:
+//   1. lane = sample: coordinates and weights  ->  a small record in LDS;
 //   2. lane = (sample, channel quad): CQ = C/4 lanes share a sample, so one wave instruction
-//      fetches 64/CQ whole 16*CQ-byte node vectors (the L1 sees each node line once instead of
-//      CQ times), the payload row of a sample leaves as one contiguous 16*CQ-byte store, and the
-//      channel sums for grad_grid are finished with CQ-lane shuffles.
+//      fetches 64/CQ whole 16*CQ-byte node rows (the L1 sees each node line once, not CQ times).
+// The backward point kernels keep lane = sample throughout: their extra stream (gOut) is read as
+// 256 contiguous bytes per wave per channel, which measured faster than 64-byte segments.
 // ------------------------------------------------------------------------------------------------
 // Stream accesses (each element touched once per kernel) are marked nontemporal so that they do
 // not displace the feature table from L2 / Infinity Cache.
@@ -253,26 +252,23 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // record fields (one float/uint per sample, SoA over the wave's 64 samples)
-enum { R_NODE = 0, R_WX0 = 4, R_WX1, R_WY0, R_WY1, R_D1X, R_D1Y, R_D2X, R_D2Y, R_SLOT, R_CGX, R_CGY, R_HGX, R_HGY,
-       R_FIELDS };
+enum { R_NODE = 0, R_WX0 = 4, R_WX1, R_WY0, R_WY1, R_FIELDS };
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 constexpr int REC_FLOATS = R_FIELDS * 64;   // per wave
 
-// phase 1: lane = sample.  Returns nothing; everything phase 2 needs is in `rec`.
-template <int KERNEL, int ORDER>
-__device__ __forceinline__ void point_phase1(float *rec, const float *grid, const float *offset,
-                                             const uint32_t *rank, const float *cG, const float *hG, const Dims &d,
+// phase 1 of point_forward: lane = sample; everything phase 2 needs goes to `rec`
+template <int KERNEL>
+__device__ __forceinline__ void point_phase1(float *rec, const float *grid, const float *offset, const Dims &d,
                                              const Flags &f, int align) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.y;
     int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = p < d.P;
-    if (!live) p = d.P - 1;
+    if (p >= d.P) p = d.P - 1;
     const int64_t s = (int64_t)n * d.P + p;
     const float off = offset[n];
     float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
-    Axis ax = make_axis<KERNEL, ORDER>(g.x, d.size[0], f, align, off);
-    Axis ay = make_axis<KERNEL, ORDER>(g.y, d.size[1], f, align, off);
+    Axis ax = make_axis<KERNEL, 0>(g.x, d.size[0], f, align, off);
+    Axis ay = make_axis<KERNEL, 0>(g.y, d.size[1], f, align, off);
     uint32_t *ru = reinterpret_cast<uint32_t *>(rec);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -284,31 +280,6 @@ __device__ __forceinline__ void point_phase1(float *rec, const float *grid, cons
     rec[R_WX1 * 64 + lane] = ax.w[1];
     rec[R_WY0 * 64 + lane] = ay.w[0];
     rec[R_WY1 * 64 + lane] = ay.w[1];
-    if (ORDER >= 1) {
-        rec[R_D1X * 64 + lane] = ax.d1;
-        rec[R_D1Y * 64 + lane] = ay.d1;
-    }
-    if (ORDER >= 2) {
-        rec[R_D2X * 64 + lane] = ax.d2;
-        rec[R_D2Y * 64 + lane] = ay.d2;
-    }
-    ru[R_SLOT * 64 + lane] = (live && rank) ? rank[s] : INVALID;
-    if (cG) {
-        float2 c = *reinterpret_cast<const float2 *>(cG + s * 2);
-        rec[R_CGX * 64 + lane] = c.x;
-        rec[R_CGY * 64 + lane] = c.y;
-    } else if (ORDER >= 2) {
-        rec[R_CGX * 64 + lane] = 0.f;
-        rec[R_CGY * 64 + lane] = 0.f;
-    }
-    if (hG) {
-        float2 h = *reinterpret_cast<const float2 *>(hG + s * 2);
-        rec[R_HGX * 64 + lane] = h.x;
-        rec[R_HGY * 64 + lane] = h.y;
-    } else if (ORDER >= 2) {
-        rec[R_HGX * 64 + lane] = 0.f;
-        rec[R_HGY * 64 + lane] = 0.f;
-    }
 }
 
 // what a phase-2 lane knows about its sample
@@ -356,14 +327,6 @@ __device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o) {
     st_stream(dst + 2 * P, o.z);
     st_stream(dst + 3 * P, o.w);
 }
-// sum over the CQ lanes of a sample (lanes of one sample are adjacent)
-template <int CQ>
-__device__ __forceinline__ float quad_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < CQ; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 template <int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
                                                      const float *__restrict__ offset, float *__restrict__ out,
@@ -371,7 +334,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     extern __shared__ float lds[];
     constexpr int C = 4 * CQ;
     float *rec = lds + (threadIdx.x >> 6) * REC_FLOATS;
-    point_phase1<KERNEL, 0>(rec, grid, offset, nullptr, nullptr, nullptr, d, f, 1);  // 2D fwd: align = 1 (2d.cu:307-308)
+    point_phase1<KERNEL>(rec, grid, offset, d, f, 1);   // 2D forward: align_corners = 1 (2d.cu:307-308)
     __syncthreads();
     const int n = blockIdx.y;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);

@@ -159,6 +159,62 @@ def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared):
         assert_close(got[k], want[k], "rows d=%d C=%d kernel=%d pad=%d align=%s mc=%s: %s" % (d, C, ke, pad, align, mc, k))
 
 
+@pytest.mark.parametrize("d,C", [(2, 16), (2, 4), (3, 8)])
+def test_autograd_chain_on_fast_paths_vs_composite(d, C):
+    """Large enough for the fast paths (2D: tiled, 3D: channels-last + row scatter) to be chosen by the
+    library itself; driven through torch.autograd to third order with one StepContext per forward, and
+    compared with the exact-derivative composite evaluated on the GPU (axis-aligned second/third
+    order, where the op and the exact derivative agree: DESIGN.md section 2)."""
+    from oracle import composite
+    torch.manual_seed(5)
+    N, S, P = 4, 48, 40000
+    cells = torch.rand((N, C) + (S,) * d, device=DEV, requires_grad=True)
+    coords = [(torch.rand(P, 1, device=DEV) * 2 - 1).requires_grad_(True) for _ in range(d)]
+    grid = torch.cat(coords, -1).view((1,) * d + (P, d)).repeat((N,) + (1,) * (d + 1))
+    w = torch.randn((N, C) + (1,) * (d - 1) + (P,), device=DEV)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+
+    def quantities(sample):
+        out = sample(cells, grid)
+        u = (out * w).sum(dim=(0, 1)).view(P, 1)
+        res = {"u": u}
+        g = lambda y, x: torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True, create_graph=True)[0]
+        res["u_cell"] = g(u, cells)
+        for j, nm in enumerate("xyz"[:d]):
+            uj = g(u, coords[j])
+            ujj = g(uj, coords[j])
+            res["u_" + nm], res["u_" + nm * 2] = uj, ujj
+            res["u_%s_cell" % nm], res["u_%s_cell" % (nm * 2)] = g(uj, cells), g(ujj, cells)
+        return {k: v.detach() for k, v in res.items()}
+
+    got = quantities(lambda c, g_: Fn.apply(c, g_, "zeros", True, "cosine", True))
+    want = quantities(lambda c, g_: composite.grid_sample_nd(c, g_, "cosine", True, True))
+    for k in want:
+        assert_close(got[k], want[k], "autograd %dD C=%d %s" % (d, C, k), tol=2e-5)
+
+
+def test_step_context_follows_in_place_updates():
+    """The channels-last copy is keyed on the tensor's version counter: an optimizer step on `cells`
+    between two uses of one context must not serve stale values."""
+    torch.manual_seed(6)
+    N, C, S, P = 4, 16, 32, 30000
+    cells = torch.rand(N, C, S, S, device=DEV)
+    grid = torch.rand(N, 1, P, 2, device=DEV) * 2 - 1
+    off = multicell_offset(N, True, DEV)
+    step = ops.StepContext()
+    a = ops.forward(cells, grid, off, 0, True, 0, True, ctx=step)
+    cells.mul_(2.0)
+    b = ops.forward(cells, grid, off, 0, True, 0, True, ctx=step)
+    assert rel_err(b, a * 2.0) <= 1e-6
+    grid2 = grid.clone()
+    grid2[..., 0] = -grid2[..., 0]
+    gOut = torch.randn_like(a)
+    g1, _ = ops.backward(gOut, cells, grid, off, 0, True, True, 0, True, ctx=step)
+    g2, _ = ops.backward(gOut, cells, grid2, off, 0, True, True, 0, True, ctx=step)     # new grid -> new plan
+    r2, _ = ops.backward(gOut, cells, grid2, off, 0, True, True, 0, True)
+    assert rel_err(g2, r2) <= 1e-5 and rel_err(g1, r2) > 1e-2
+
+
 def test_tiled_path_empty_and_clustered_points():
     """Degenerate point sets for the plan: every point in one cell, every point out of range."""
     N, C, sp = 2, 16, (40, 33)
