@@ -215,6 +215,20 @@ def test_step_context_follows_in_place_updates():
     assert rel_err(g2, r2) <= 1e-5 and rel_err(g1, r2) > 1e-2
 
 
+@pytest.mark.parametrize("C", [4, 16])
+def test_tiled_path_crowded_tiles(C):
+    """PIXEL-like shape (reference test/test_2d.py: 16x16 cells, 1e5 points): a tile holds tens of
+    thousands of samples, so several workgroups share it (tile_scatter_split)."""
+    N, P, sp = 3, 40000, (16, 16)
+    t = _case(2, N, C, sp, P, seed=4242 + C, spread=1.0)
+    off = offsets(N, True)
+    want = _run_all_stages(cs_oracle, t, off, 0, True, 0, True, "cpu")
+    got = _run_all_stages(_Shared(), t, off, 0, True, 0, True, DEV)      # S = 120000: tiled path by itself
+    torch.cuda.synchronize()
+    for k in want:
+        assert_close(got[k], want[k], "crowded C=%d: %s" % (C, k))
+
+
 def test_tiled_path_empty_and_clustered_points():
     """Degenerate point sets for the plan: every point in one cell, every point out of range."""
     N, C, sp = 2, 16, (40, 33)

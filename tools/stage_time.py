@@ -8,8 +8,9 @@ from cosinesampler_amd import multicell_offset, ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda", 0)
-N, C, H, P = 16, 16, int(sys.argv[2]) if len(sys.argv) > 2 else 256, 1 << 20
-print("H=W=%d" % H)
+N, C, H, P = 16, int(os.environ.get("CS_C", "16")), int(sys.argv[2]) if len(sys.argv) > 2 else 256, 1 << 20
+N = int(os.environ.get("CS_N", N)); P = int(os.environ.get("CS_P", P))
+print("N=%d C=%d H=W=%d P=%d" % (N, C, H, P))
 torch.manual_seed(0)
 cells = torch.rand(N, C, H, H, device=dev)
 xy = torch.rand(P, 2, device=dev) * 2 - 1
