@@ -85,6 +85,42 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
                       "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
 
 
+def helmholtz_step(N, C, H, P, dev, steps=3):
+    """BASELINE.json configs[2]: the PIXEL-style Helmholtz step driven entirely by torch.autograd
+    (reference test/test_2d.py pattern): u = MLP(sum_n sampler(cells, grid)); u_x, u_y; u_xx, u_yy via the
+    second backward; loss = mean((u_xx + u_yy + k^2 u)^2); d loss / d cells via the third backward.
+    Returns average milliseconds per step (HIP events), first step excluded."""
+    from cosinesampler_amd import CosineSampler2d
+    g = torch.Generator(device="cpu").manual_seed(7)
+    cells = torch.rand(N, C, H, H, generator=g).to(dev).requires_grad_(True)
+    W1 = (torch.randn(16, C, generator=g) * 0.5).to(dev)
+    W2 = (torch.randn(1, 16, generator=g) * 0.5).to(dev)
+    x = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    y = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    ones = torch.ones(P, 1, device=dev)
+
+    def one():
+        grid = torch.cat([x, y], -1).view(1, 1, P, 2).repeat(N, 1, 1, 1)
+        val = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
+        u = torch.tanh(val.sum(0).view(C, -1).t() @ W1.t()) @ W2.t()
+        u_x, u_y = torch.autograd.grad(u, (x, y), ones, create_graph=True)
+        (u_xx,) = torch.autograd.grad(u_x, x, ones, create_graph=True)
+        (u_yy,) = torch.autograd.grad(u_y, y, ones, create_graph=True)
+        loss = torch.mean((u_xx + u_yy + 4.0 * u) ** 2)
+        (gc,) = torch.autograd.grad(loss, cells)
+        return gc
+
+    one()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        one()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1 << 20, help="P per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-helmholtz", action="store_true", help="skip the extra autograd-driven PIXEL step timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +169,7 @@ def main():
 
     stage_names = ["forward", "backward", "backward_backward", "bbb_fused"]
     ev = []
+    out_keep = []
 
     def step(record):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
@@ -220,6 +258,14 @@ def main():
             "stages_ms": stage_ms,
             "stages_frac": {k: ab[k] / (stage_ms[k] * 1e-3) / HBM_PEAK for k in stage_names},
         }
+        if world == 1 and not args.no_helmholtz:
+            del out_keep[:]
+            ms = helmholtz_step(N, C, H, P, dev)
+            line["pixel_helmholtz_autograd"] = {
+                "ms_per_step": ms, "Msamples_per_s": S / ms / 1e3,
+                "what": "configs[2]: CosineSampler2d.apply -> sum over n -> MLP -> u_x,u_y -> u_xx,u_yy -> "
+                        "d mean((u_xx+u_yy+4u)^2)/d cells, all through torch.autograd (incl. its .contiguous() "
+                        "copies of the expanded gradients and the MLP), same N,C,H,W,P"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, C, H)
         print(json.dumps(line), flush=True)
