@@ -282,7 +282,7 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     if (stage == CS_STAGE_FORWARD) return need;
     if (!have_plan) need += plan_layout(N, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : C + 4) * 4);   // fat rows
+    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : (stage == CS_STAGE_BACKWARD ? C + 8 : C + 4)) * 4);   // fat rows
     return need;
 }
 
@@ -346,21 +346,28 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
                    size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
-    // without grad_input nothing is scattered: no plan, no fat rows
+    // without grad_input nothing is scattered: no plan, no fat rows -- the point kernel gathers and is all there is
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *fat = nullptr;
-    if (grad_input) {
-        fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
-        if (!ws.ok()) return CS_ERR_WORKSPACE;
-        rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
-        if (rc) return rc;
+    if (!grad_input) {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+                                          gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
+        return launch_status();
     }
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
-                                      gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
+    // with grad_input: streams -> fat rows (no gathers), then the tile walkers produce grad_input AND grad_grid
+    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 8) * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    if (rc) return rc;
+    size_t shm = (size_t)256 * (pb.d.C + 8) * 4;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward_rows<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                                      gOut, grid, offset, fat, pb.d, pb.f))));
     rc = launch_status();
-    if (rc || !grad_input) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, fat, grad_input);
+    if (rc) return rc;
+    tl::zero_dropped_grid_grads<<<point_grid(pb), kBlock, 0, pb.stream>>>(grid, offset, grad_grid, pr.plan, pb.d, pb.f);
+    unsigned nb = (unsigned)((int64_t)pb.d.N * pr.plan.ntiles);
+    CS_DISPATCH_CQ(pb.d.C, (tl::tile_backward<CQ><<<nb, 256, 0, pb.stream>>>(fat, pr.icl, pr.plan, grad_input, grad_grid, pb.d)));
+    return launch_status();
 }
 
 int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
