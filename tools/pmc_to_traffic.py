@@ -25,7 +25,8 @@ T = 16 * 16 * 256 * 256 * 4
 plan = sum(kb("cs::tiled::" + k) for k in ("plan_count", "plan_scan_chunks", "plan_scan_tiles", "plan_scatter", "plan_tile_sort"))
 stage = {
     "forward": kb("cs::tiled::pack_channels_last") + kb("cs::tiled::point_forward"),
-    "backward": plan + kb("cs::tiled::point_backward") + kb("cs::tiled::tile_scatter<4, false>") + T,
+    "backward": plan + kb("cs::tiled::point_backward_rows") + kb("cs::tiled::zero_dropped_grid_grads")
+                + kb("cs::tiled::tile_backward") + T,
     "backward_backward": kb("cs::tiled::point_bb") + kb("cs::tiled::tile_scatter<4, false>") + T,
     "bbb_fused": kb("cs::tiled::point_bbb") + kb("cs::tiled::tile_scatter<4, true>") + T,
 }
