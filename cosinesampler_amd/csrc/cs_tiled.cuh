@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
 #ifndef CS_NT_STREAMS
 #define CS_NT_STREAMS 1
 #endif
+// sc1 store (agent-scope relaxed): written through and DROPPED from the XCD's L2, so a 1 GiB output stream
+// leaves the 4 MiB table slice in place.  Only worth it when a wave instruction writes whole lines
+// (lane = sample kernels: 256 contiguous bytes); with point_forward's 64-byte segments it measured 45 %
+// slower than the nontemporal store, which is why both exist.
+__device__ __forceinline__ void st_stream_wt(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void st_stream(float *p, float v) {
 #if CS_NT_STREAMS
     __builtin_nontemporal_store(v, p);
@@ -423,7 +430,13 @@ __device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 
 template <int CQ>
 __device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4 (&o)[CQ]) {
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) store_quad(dst + (int64_t)(4 * q) * P, P, o[q]);
+    for (int q = 0; q < CQ; ++q) {
+        float *p = dst + (int64_t)(4 * q) * P;
+        st_stream_wt(p, o[q].x);
+        st_stream_wt(p + P, o[q].y);
+        st_stream_wt(p + 2 * P, o[q].z);
+        st_stream_wt(p + 3 * P, o[q].w);
+    }
 }
 // fat row of sample s: payload(s) then coefficient record(s), contiguous, 16-byte aligned.
 // A lane first puts its row into the wave's LDS stage; flush_rows then streams the wave's 64 rows
@@ -446,7 +459,7 @@ __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         int item = i * 64 + lane;
-        if (item < nlive * PIECES) dst[item] = src[item];
+        if (item < nlive * PIECES) dst[item] = src[item];   // (sc1 here measured no better)
     }
 }
 
