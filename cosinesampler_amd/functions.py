@@ -81,13 +81,34 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+# dtypes: the kernels are fp32 (include/cosine_sampler.h).  The reference dispatches double/float/half
+# (2d.cu:905) but evaluates the blending weights and their derivatives in `float` whatever the tensor
+# type (2d.cu:239-261, :430-431), so float64/float16/bfloat16 tensors are served by
+# converting at this boundary: fp32 math, results cast back to the dtype of the tensor they are the
+# gradient (or output) of.  Not a native path -- each stage pays the conversion copies.
+_FLOATS = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
+
+
+def _f32(t):
+    if t is None or t.dtype == torch.float32:
+        return t
+    if t.dtype not in _FLOATS:
+        raise RuntimeError("CosineSampler expects floating-point tensors, got %s" % t.dtype)
+    return t.float()
+
+
+def _as(t, like):
+    return t if t is None or t.dtype == like.dtype else t.to(like.dtype)
+
+
 def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multicell):
     if input.dim() != dim + 2:
         raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
     cfg = _Config(padding_mode, align_corners, kernel, multicell)
     offset = multicell_offset(input.shape[0], multicell, input.device)
     step = ops.StepContext()   # channels-last input copy + point plan, shared by this call's backward chain
-    output = ops.forward(input, grid, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step)
+    output = _as(ops.forward(_f32(input), _f32(grid), offset, cfg.pad, cfg.align_corners, cfg.kernel,
+                             cfg.multicell, ctx=step), input)
     ctx.save_for_backward(input, grid)
     ctx.offset = offset
     ctx.cfg = cfg
@@ -136,10 +157,11 @@ class _SamplerBackward(Function):
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
-        grad_input, grad_grid = ops.backward(gOut, input, grid, offset, cfg.pad, cfg.align_corners,
-                                             bool(input_requires_grad), cfg.kernel, cfg.multicell, ctx=step)
+        grad_input, grad_grid = ops.backward(_f32(gOut), _f32(input), _f32(grid), offset, cfg.pad,
+                                             cfg.align_corners, bool(input_requires_grad), cfg.kernel, cfg.multicell,
+                                             ctx=step)
         ctx.save_for_backward(input, grid, gOut)
-        return grad_input, grad_grid
+        return _as(grad_input, input), _as(grad_grid, grid)
 
     @staticmethod
     def backward(ctx, gOutInput, gOutGrid):
@@ -161,9 +183,10 @@ class _SamplerBackwardBackward(Function):
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
-        gInput, gGrid, ggOut = ops.backward_backward(gOutInput, gOutGrid, input, grid, gOut, offset, cfg.pad,
-                                                     cfg.align_corners, gOutInput is not None, cfg.kernel,
-                                                     cfg.multicell, ctx=step)
+        gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
+                                                     _f32(gOut), offset, cfg.pad, cfg.align_corners,
+                                                     gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step)
+        gInput, gGrid, ggOut = _as(gInput, input), _as(gGrid, grid), _as(ggOut, gOut)
         ctx.has_cG = gOutGrid is not None
         if gOutGrid is None:
             ctx.save_for_backward(input, grid, gOut)
@@ -182,6 +205,7 @@ class _SamplerBackwardBackward(Function):
         if gOutgGrid is None and gOutggOut is None:
             return None, None, None, None, None, None, None, None
         cfg = ctx.cfg
-        gInput, ggOut = ops.bbb_fused(input, grid, gOut, gOutGrid, _c(gOutgGrid), _c(gOutggOut), ctx.offset,
-                                      cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
-        return gInput, None, ggOut, None, None, None, None, None
+        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), _f32(_c(gOutgGrid)),
+                                      _f32(_c(gOutggOut)), ctx.offset, cfg.pad, cfg.align_corners, cfg.kernel,
+                                      cfg.multicell, ctx=ctx.step)
+        return _as(gInput, input), None, _as(ggOut, gOut), None, None, None, None, None

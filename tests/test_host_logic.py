@@ -90,6 +90,26 @@ def test_grad_input_skipped_when_input_does_not_require_grad(monkeypatch):
     assert gG.shape == grid.shape
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
+def test_other_float_dtypes_convert_at_the_boundary(monkeypatch, dtype):
+    """The reference dispatches double/float/half (2d.cu:905); here they are served through fp32."""
+    oracle_backend.install(monkeypatch)
+    g = torch.Generator().manual_seed(1)
+    cells32 = torch.rand(2, 3, 8, 8, generator=g)
+    grid32 = torch.rand(2, 1, 40, 2, generator=g) * 2 - 1
+    ref = CosineSampler2d.apply(cells32, grid32)
+    cells = cells32.to(dtype).requires_grad_(True)
+    grid = grid32.to(dtype).requires_grad_(True)
+    out = CosineSampler2d.apply(cells, grid)
+    assert out.dtype == dtype
+    tol = 1e-6 if dtype == torch.float64 else 2e-3
+    assert float((out.detach().float() - ref).abs().max()) <= tol * float(ref.abs().max())
+    gI, gG = torch.autograd.grad(out.sum(), (cells, grid), create_graph=True)
+    assert gI.dtype == dtype and gG.dtype == dtype
+    (gg,) = torch.autograd.grad(gG[..., 0].sum(), cells)
+    assert gg.dtype == dtype and gg.shape == cells.shape
+
+
 def test_drop_in_package_names():
     import cosine_sampler_2d
     import cosine_sampler_3d

@@ -193,6 +193,25 @@ def test_autograd_chain_on_fast_paths_vs_composite(d, C):
         assert_close(got[k], want[k], "autograd %dD C=%d %s" % (d, C, k), tol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16, torch.bfloat16])
+def test_other_float_dtypes_on_gpu(dtype):
+    """double / half / bfloat16 tensors are converted at the autograd boundary (fp32 kernels)."""
+    torch.manual_seed(9)
+    cells32 = torch.rand(3, 4, 12, 12, device=DEV)
+    grid32 = torch.rand(3, 1, 500, 2, device=DEV) * 2 - 1
+    ref = CosineSampler2d.apply(cells32, grid32, "zeros", True, "cosine", True)
+    cells = cells32.to(dtype).requires_grad_(True)
+    grid = grid32.to(dtype).requires_grad_(True)
+    out = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
+    assert out.dtype == dtype
+    if dtype == torch.float64:
+        assert rel_err(out, ref) <= 1e-6
+    gI, gG = torch.autograd.grad(out.sum(), (cells, grid), create_graph=True)
+    assert gI.dtype == dtype and gG.dtype == dtype and torch.isfinite(gI.float()).all()
+    (gc,) = torch.autograd.grad(gG[..., 1].sum(), cells)
+    assert gc.dtype == dtype and gc.shape == cells.shape
+
+
 def test_step_context_follows_in_place_updates():
     """The channels-last copy is keyed on the tensor's version counter: an optimizer step on `cells`
     between two uses of one context must not serve stale values."""
@@ -349,8 +368,10 @@ def test_edge_shapes(d):
     grid = torch.rand((2,) + (1,) * (d - 1) + (9, d), device=DEV)
     with pytest.raises(RuntimeError, match="contiguous"):
         Fn.apply(inp.transpose(-1, -2), grid)
-    with pytest.raises(RuntimeError, match="float32"):
-        Fn.apply(inp.double(), grid.double())
+    with pytest.raises(RuntimeError, match="float32"):       # the op layer itself is fp32-only ...
+        ops.forward(inp.double(), grid.double(), multicell_offset(2, True, DEV), 0, True, 0, True)
+    with pytest.raises(RuntimeError, match="floating-point"):   # ... and the autograd layer converts floats only
+        Fn.apply(inp.long(), grid)
     with pytest.raises(RuntimeError, match="grid must be"):
         Fn.apply(inp, grid[:1])
 
