@@ -3,6 +3,7 @@
 // Nothing here allocates, frees, copies to the host or synchronises.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "../../include/cosine_sampler.h"
@@ -327,7 +328,13 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
 
 dim3 point_grid(const Problem &pb) { return dim3((unsigned)((pb.d.P + kBlock - 1) / kBlock), (unsigned)pb.d.N); }
 
-size_t fat_lds(int C, bool two) { return (size_t)256 * (two ? 2 * C + 8 : C + 4) * 4; }   // 4 waves x 64 fat rows
+// 4 waves x 64 fat rows.  The two-payload third-backward kernel is given 56 KiB whatever it needs: that
+// caps it at 2 resident workgroups per CU, which measured 5 % faster than the 4 its registers allow
+// (fewer concurrent streams fighting the table slice for the L2); the one-payload kernels showed no such gain.
+size_t fat_lds(int C, bool two) {
+    size_t need = (size_t)256 * (two ? 2 * C + 8 : C + 4) * 4;
+    return two ? std::max(need, (size_t)56 * 1024) : need;
+}   // 4 waves x 64 fat rows
 size_t point_lds() { return (size_t)4 * tl::REC_FLOATS * 4; }   // one geometry record block per wave
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
