@@ -34,6 +34,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 
+# what each timed stage launches at this config (names as rocprofv3 prints them, profiles/round1_kernel_stats.csv);
+# a stage's HIP-event time is the sum of these plus the 64 MiB clear of its grad_input
+STAGE_KERNELS = {
+    "forward": ["cs::tiled::pack_channels_last", "cs::tiled::point_forward<0, 4>"],
+    "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward_rows<0, 4>",
+                 "cs::tiled::zero_dropped_grid_grads", "cs::tiled::tile_backward<4>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false>", "cs::tiled::tile_scatter<4, false>"],
+    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true>", "cs::tiled::tile_scatter<4, true>"],
+}
+
 
 def algorithmic_bytes(S, C, d, T):
     """BASELINE.md section 3 / SURVEY.md 8(d): compulsory traffic, every tensor element once."""
@@ -251,7 +261,7 @@ def main():
                                    "forward + backward + backward_backward + fused third backward%s"
                                    % (P, " + 1 RCCL all-reduce of grad_input (64 MiB)" if world > 1 else ""),
                        "samples_per_step_per_gpu": S, "sharding": "points (P) across ranks"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": dom, "kernels": STAGE_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]},
             "pipeline_roofline_frac": total_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
