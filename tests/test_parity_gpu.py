@@ -193,6 +193,50 @@ def test_autograd_chain_on_fast_paths_vs_composite(d, C):
         assert_close(got[k], want[k], "autograd %dD C=%d %s" % (d, C, k), tol=2e-5)
 
 
+@pytest.mark.parametrize("d", [2, 3])
+def test_reference_test_scripts_at_their_own_shapes(d):
+    """The reference's two test scripts at their real sizes (test/test_2d.py:20-40: 96 cells of 4x16x16,
+    100 000 points; test/test_3d.py:14-34: 50 cells of 4x16^3), same quantities, with this repo's composite
+    (validated against the reference's ground truth, tests/test_oracle_golden.py) standing in for
+    test/grid_sampler.py, and the reference's own acceptance test: rtol 1e-4 on d loss / d cells."""
+    from oracle import composite
+    torch.manual_seed(51 if d == 2 else 6)
+    n_cell, cell_dim, numb = (96, 4, 100000) if d == 2 else (50, 4, 100000)
+    cells = torch.rand((n_cell, cell_dim) + (16,) * d, device=DEV, requires_grad=True)
+    # Second derivatives of the cosine kernel JUMP at cell boundaries (k''(0) = -k''(1)), so a sample whose
+    # source index lands within rounding error of an integer may legitimately fall on either side: the op
+    # fuses x*(size-2)+offset into one fmaf like a GPU build of the reference, torch's composite rounds twice.
+    # With n_cell offsets n/n_cell per point, random points always have some n that close to a boundary; draw
+    # the points on the lattice i = (k + 1/2)/n_cell instead, half a lattice step away from every boundary.
+    def lattice():
+        k = torch.randint(0, 14 * n_cell, (numb, 1), device=DEV).double()
+        return (2.0 * ((k + 0.5) / n_cell) / 14.0 - 1.0).float().requires_grad_(True)
+    coords = [lattice() for _ in range(d)]
+    net = torch.nn.Sequential(torch.nn.Linear(cell_dim, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1)).to(DEV)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+
+    def run(sample):
+        grid = torch.cat(coords, -1).view((1,) * d + (numb, d)).repeat((n_cell,) + (1,) * (d + 1))
+        val = net(sample(cells, grid).sum(0).view(cell_dim, -1).t())
+        g = lambda y, x: torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True, create_graph=True)[0]
+        firsts = [g(val, c) for c in coords]
+        seconds = [g(f, c) for f, c in zip(firsts, coords)]
+        if d == 2:   # test_2d.py:221
+            f_pred = firsts[1] * 2 + 5 * (val ** 3) - 5 * val - 0.0001 * seconds[0]
+        else:        # test_3d.py:270
+            f_pred = seconds[0] + seconds[1] + seconds[2] + val
+        res = dict(val=val, u_cell=g(val, cells), u_x=firsts[0], u_xx=seconds[0], u_xx_cell=g(seconds[0], cells))
+        res["dloss"] = torch.autograd.grad(torch.mean(f_pred ** 2), cells)[0]      # last: frees the graph
+        return {k: v.detach() for k, v in res.items()}
+
+    got = run(lambda c, g_: Fn.apply(c, g_, "zeros", True, "cosine", True))
+    want = run(lambda c, g_: composite.grid_sample_nd(c, g_, "cosine", True, True))
+    for k in want:
+        assert_close(got[k], want[k], "reference test_%dd shapes: %s" % (d, k), tol=2e-5)
+    a, b = got["dloss"].detach().cpu(), want["dloss"].detach().cpu()
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))     # test_2d.py:244 / test_3d.py:293
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float16, torch.bfloat16])
 def test_other_float_dtypes_on_gpu(dtype):
     """double / half / bfloat16 tensors are converted at the autograd boundary (fp32 kernels)."""
