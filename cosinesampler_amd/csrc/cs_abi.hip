@@ -382,7 +382,8 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
-    int rc = prepare(pb, CS_STAGE_BACKWARD_BACKWARD, input, grid, offset, input_cl, plan, ws, pr);
+    // without gInput nothing is scattered: no plan, no fat rows
+    int rc = prepare(pb, gInput ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
@@ -392,10 +393,23 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         if (rc) return rc;
         cIcl = buf;
     }
-    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
-    if (!ws.ok()) return CS_ERR_WORKSPACE;
-    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
-    if (rc) return rc;
+    float *fat = nullptr;
+    if (gInput) {
+        fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+    }
+    if (!gInput) {
+        if (cIcl) {
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+                                              cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
+        } else {
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+                                              cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
+        }
+        return launch_status();
+    }
     if (cIcl) {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
                                           cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
@@ -505,7 +519,7 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
                                           nullptr, cG, icl, grid, gOut, offset, gGrid, ggOut, pb.d, pb.f))));
     }
     rc = launch_status();
-    if (rc) return rc;
+    if (rc || !gInput) return rc;
     float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     return row_scatter_into<DIM, 1>(pb, grid, offset, gOut, cG, nullptr, nullptr, gInput, acc);
@@ -649,14 +663,14 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
                            void *stream) {
     CS_PROBLEM(2, 1)
-    CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
+    CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     if (tiled)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bb<2>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
-        if (rc) return rc;
+        if (rc || !grad_input) return rc;
         return run_row_scatter<2, 1>(pb, grid, offset, grad_output, grad_out_grid, nullptr, nullptr, grad_input,
                                      workspace, workspace_bytes);
     }
@@ -744,14 +758,14 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
                            void *stream) {
     CS_PROBLEM(3, D)
-    CS_NEED(input, grid, grad_output, offset, grad_input, grad_grid, grad_grad_out)
+    CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                          grad_grad_out, input_cl, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bb<3>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
-        if (rc) return rc;
+        if (rc || !grad_input) return rc;
         return run_row_scatter<3, 1>(pb, grid, offset, grad_output, grad_out_grid, nullptr, nullptr, grad_input,
                                      workspace, workspace_bytes);
     }

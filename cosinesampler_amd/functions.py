@@ -101,6 +101,30 @@ def _as(t, like):
     return t if t is None or t.dtype == like.dtype else t.to(like.dtype)
 
 
+def _engine_wants(ctx, i):
+    """Will the running backward pass use the gradient this node returns for its i-th forward input?
+    `ctx.needs_input_grad` only says that the input requires grad; under
+    `torch.autograd.grad(u, x, create_graph=True)` -- every derivative a PINN takes -- the gradient w.r.t.
+    the cell table is computed by the reference (input_requires_grad is True, modules_2d.py:44) and dropped
+    by the engine.  Asking the engine lets those calls skip the scatter half of the stage.  Whenever the
+    question cannot be answered (leaf input inside autograd.grad, no graph task, ...) the answer is yes."""
+    if not ctx.needs_input_grad[i]:
+        return False
+    try:
+        node = ctx.next_functions[i][0]
+        return node is None or bool(torch._C._will_engine_execute_node(node))
+    except Exception:   # noqa: BLE001 -- any doubt: compute it
+        return True
+
+
+def _through_view(input):
+    """The engine only answers `_engine_wants` for non-leaf nodes while autograd.grad() runs; a leaf table
+    (the usual nn.Parameter) therefore enters the op through a no-copy autograd view."""
+    if isinstance(input, torch.Tensor) and input.requires_grad and input.grad_fn is None and torch.is_grad_enabled():
+        return input.view_as(input)
+    return input
+
+
 def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multicell):
     if input.dim() != dim + 2:
         raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
@@ -121,11 +145,15 @@ def _backward(ctx, grad_out):
     if grad_out is None:
         return None, None, None, None, None, None
     d_input, d_grid = _SamplerBackward.apply(input, grid, _c(grad_out), ctx.offset, ctx.cfg,
-                                             ctx.needs_input_grad[0], ctx.step)
+                                             _engine_wants(ctx, 0), ctx.step)
     return d_input, d_grid, None, None, None, None
 
 
 class CosineSampler2d(Function):
+    @classmethod
+    def apply(cls, input, *args, **kwargs):
+        return super().apply(_through_view(input), *args, **kwargs)
+
     @staticmethod
     def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
         ctx.set_materialize_grads(False)
@@ -137,6 +165,10 @@ class CosineSampler2d(Function):
 
 
 class CosineSampler3d(Function):
+    @classmethod
+    def apply(cls, input, *args, **kwargs):
+        return super().apply(_through_view(input), *args, **kwargs)
+
     @staticmethod
     def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
         ctx.set_materialize_grads(False)
@@ -169,7 +201,7 @@ class _SamplerBackward(Function):
         if gOutInput is None and gOutGrid is None:
             return None, None, None, None, None, None, None
         gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
-                                                              ctx.offset, ctx.cfg, ctx.step)
+                                                              ctx.offset, ctx.cfg, ctx.step, _engine_wants(ctx, 0))
         return gInput, gGrid, ggOut, None, None, None, None
 
 
@@ -178,14 +210,15 @@ class _SamplerBackwardBackward(Function):
     CosineSamplerBackwardBackward, modules_2d.py:76-111."""
 
     @staticmethod
-    def forward(ctx, input, grid, gOut, gOutInput, gOutGrid, offset, cfg, step):
+    def forward(ctx, input, grid, gOut, gOutInput, gOutGrid, offset, cfg, step, want_grad_input=True):
         ctx.set_materialize_grads(False)
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
         gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
                                                      _f32(gOut), offset, cfg.pad, cfg.align_corners,
-                                                     gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step)
+                                                     gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step,
+                                                     want_grad_input=bool(want_grad_input))
         gInput, gGrid, ggOut = _as(gInput, input), _as(gGrid, grid), _as(ggOut, gOut)
         ctx.has_cG = gOutGrid is not None
         if gOutGrid is None:
@@ -203,9 +236,9 @@ class _SamplerBackwardBackward(Function):
         else:
             (input, grid, gOut), gOutGrid = ctx.saved_tensors, None
         if gOutgGrid is None and gOutggOut is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         cfg = ctx.cfg
         gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), _f32(_c(gOutgGrid)),
                                       _f32(_c(gOutggOut)), ctx.offset, cfg.pad, cfg.align_corners, cfg.kernel,
                                       cfg.multicell, ctx=ctx.step)
-        return _as(gInput, input), None, _as(ggOut, gOut), None, None, None, None, None
+        return _as(gInput, input), None, _as(ggOut, gOut), None, None, None, None, None, None

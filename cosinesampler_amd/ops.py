@@ -169,9 +169,11 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell, ctx=None):
+                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True):
     """-> (grad_input, grad_grid, grad_grad_out).  grad_out_input is only read when
-    input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros)."""
+    input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros).
+    want_grad_input=False (not in the reference): grad_input is not computed and comes back as None --
+    the scatter half of the stage, and the point plan it needs, are skipped."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     _same(grad_output, out_shape(input, grid), "grad_output", input.device)
@@ -181,14 +183,14 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         grad_out_input = None
     if grad_out_grid is not None:
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
-    grad_input = torch.empty_like(input)
+    grad_input = torch.empty_like(input) if want_grad_input else None
     grad_grid = torch.empty_like(grid)
     grad_grad_out = torch.empty_like(grad_output)
     _call("backward_backward", dim,
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, have_cI=grad_out_input is not None)
+          want_plan=want_grad_input, have_cI=grad_out_input is not None)
     return grad_input, grad_grid, grad_grad_out
 
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 2
+#define CS_ABI_VERSION 3
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -102,10 +102,12 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
 
 /* Replaces `_cosine_2d.backward_backward` (2d.cpp:87-106 -> 2d.cu:990).
  * grad_out_input == NULL <=> input_requires_grad == false (modules_2d.py:87-89).
- * grad_out_grid == NULL is read as all zeros. */
+ * grad_out_grid == NULL is read as all zeros.
+ * grad_input == NULL: the caller has no use for d/d input of this stage (the reference always computes it and
+ * autograd throws it away when only d/d grid is asked for, e.g. u_xx = grad(u_x, x)); the scatter half is skipped. */
 int cs2d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
                            const float *input, const float *grid, const float *grad_output, const float *offset,
-                           float *grad_input, float *grad_grid, float *grad_grad_out,
+                           float *grad_input /* nullable */, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                            int padding_mode, int align_corners, int kernel, int multicell,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
@@ -147,7 +149,7 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
 
 int cs3d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
                            const float *input, const float *grid, const float *grad_output, const float *offset,
-                           float *grad_input, float *grad_grid, float *grad_grad_out,
+                           float *grad_input /* nullable */, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                            int padding_mode, int align_corners, int kernel, int multicell,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);

@@ -23,11 +23,14 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell, ctx=None):
+                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True):
     if grad_out_grid is None:
         grad_out_grid = torch.zeros_like(grid)
-    return cs_oracle.backward_backward(_f(grad_out_input), _f(grad_out_grid), _f(input), _f(grid), _f(grad_output),
-                                       offset, padding_mode, align_corners, input_requires_grad, kernel, multicell)
+    gi, gg, ggo = cs_oracle.backward_backward(_f(grad_out_input), _f(grad_out_grid), _f(input), _f(grid),
+                                              _f(grad_output), offset, padding_mode, align_corners,
+                                              input_requires_grad, kernel, multicell)
+    SKIPPED.append(not want_grad_input)
+    return (gi if want_grad_input else None), gg, ggo
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
@@ -38,6 +41,9 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
                                z if grad_out_ggrid is None else _f(grad_out_ggrid),
                                torch.zeros_like(grad_output) if grad_out_ggout is None else _f(grad_out_ggout),
                                offset, padding_mode, align_corners, kernel, multicell)
+
+
+SKIPPED = []   # per backward_backward call: was grad_input declared unwanted?
 
 
 def install(monkeypatch):

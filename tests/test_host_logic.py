@@ -90,6 +90,64 @@ def test_grad_input_skipped_when_input_does_not_require_grad(monkeypatch):
     assert gG.shape == grid.shape
 
 
+def test_unused_table_gradients_are_not_computed(monkeypatch):
+    """PINN pattern: u_x = grad(u, x, create_graph=True), u_xx = grad(u_x, x, create_graph=True), loss.backward().
+    Only loss.backward() uses d/d cells; the derivative calls must tell the op layer so (the reference computes
+    and drops them), and the final gradient must be what it is when nothing is skipped."""
+    oracle_backend.install(monkeypatch)
+    from cosinesampler_amd import ops
+    calls = []
+    real_backward = ops.backward
+
+    def spy_backward(gO, inp, grid, off, pad, align, input_requires_grad, kern, mc, ctx=None):
+        calls.append(bool(input_requires_grad))
+        return real_backward(gO, inp, grid, off, pad, align, input_requires_grad, kern, mc, ctx=ctx)
+
+    monkeypatch.setattr(ops, "backward", spy_backward)
+    torch.manual_seed(3)
+    cells0 = torch.rand(2, 2, 6, 6)
+    x0 = torch.rand(20, 1) * 1.8 - 0.9
+    y0 = torch.rand(20, 1) * 1.8 - 0.9
+
+    def step(leaf):
+        cells = cells0.clone().requires_grad_(True)
+        table = cells if leaf else cells * 1.0
+        x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+        grid = torch.cat([x, y], -1).view(1, 1, -1, 2).repeat(2, 1, 1, 1)
+        u = CosineSampler2d.apply(table, grid, "zeros", True, "cosine", True).sum((0, 1)).view(-1, 1)
+        del calls[:], oracle_backend.SKIPPED[:]
+        (u_x,) = torch.autograd.grad(u.sum(), x, create_graph=True)
+        assert calls == [False]                       # d/d cells of the first backward: dropped by the engine
+        (u_xx,) = torch.autograd.grad(u_x.sum(), x, create_graph=True)
+        assert oracle_backend.SKIPPED == [True]       # likewise for the second backward
+        loss = ((u_xx + u) ** 2).mean()
+        loss.backward()
+        assert calls[1:] and all(calls[1:]) and not any(oracle_backend.SKIPPED[1:])   # now they are wanted
+        return cells.grad.clone()
+
+    g_leaf, g_nonleaf = step(True), step(False)
+    monkeypatch.setattr("cosinesampler_amd.functions._engine_wants", lambda ctx, i: ctx.needs_input_grad[i])
+    cells = cells0.clone().requires_grad_(True)
+    x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+    grid = torch.cat([x, y], -1).view(1, 1, -1, 2).repeat(2, 1, 1, 1)
+    u = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True).sum((0, 1)).view(-1, 1)
+    (u_x,) = torch.autograd.grad(u.sum(), x, create_graph=True)
+    (u_xx,) = torch.autograd.grad(u_x.sum(), x, create_graph=True)
+    ((u_xx + u) ** 2).mean().backward()
+    assert torch.equal(g_leaf, cells.grad) and torch.equal(g_nonleaf, cells.grad)
+
+
+def test_table_gradient_is_computed_when_asked_for_directly(monkeypatch):
+    oracle_backend.install(monkeypatch)
+    cells = torch.rand(2, 2, 6, 6, requires_grad=True)
+    grid = (torch.rand(2, 1, 20, 2) * 1.8 - 0.9).requires_grad_(True)
+    out = CosineSampler2d.apply(cells, grid)
+    gI, gG = torch.autograd.grad(out.sum(), [cells, grid], create_graph=True)
+    assert gI is not None and gI.shape == cells.shape
+    (gI2,) = torch.autograd.grad(gG.sum(), cells)      # second order w.r.t. the table only
+    assert gI2.shape == cells.shape and float(gI2.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
 def test_other_float_dtypes_convert_at_the_boundary(monkeypatch, dtype):
     """The reference dispatches double/float/half (2d.cu:905); here they are served through fp32."""

@@ -159,6 +159,33 @@ def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared):
         assert_close(got[k], want[k], "rows d=%d C=%d kernel=%d pad=%d align=%s mc=%s: %s" % (d, C, ke, pad, align, mc, k))
 
 
+@pytest.mark.parametrize("d,C,force", [(2, 16, 2), (2, 4, 2), (2, 3, 0), (2, 32, 2), (3, 8, 2), (3, 3, 0), (3, 2, 2)])
+@pytest.mark.parametrize("with_cI", [False, True])
+def test_second_backward_without_table_gradient(d, C, force, with_cI):
+    """grad_input == NULL in cs{2,3}d_backward_backward (the engine told the autograd layer that d/d input of this
+    stage is not used): grad_grid and grad_grad_out must be what the full call gives, on every path."""
+    N, P = 2, 2500
+    sp = (37, 50) if d == 2 else (6, 9, 7)
+    t = _case(d, N, C, sp, P, seed=8800 + C, spread=1.15)
+    off = offsets(N, True).to(DEV)
+    inp, grid, gO, cG = _g(t["inp"]), _g(t["grid"]), _g(t["gOut"]), _g(t["cG"])
+    cI = _g(t["cI"]) if with_cI else None
+    ops.force_path(force)
+    try:
+        for shared in (False, True):
+            step = ops.StepContext() if shared else None
+            full = ops.backward_backward(cI, cG, inp, grid, gO, off, 0, True, with_cI, 0, True, ctx=step)
+            part = ops.backward_backward(cI, cG, inp, grid, gO, off, 0, True, with_cI, 0, True, ctx=step,
+                                         want_grad_input=False)
+            torch.cuda.synchronize()
+            assert part[0] is None
+            # separately compiled kernel variants: same formulas, the compiler may fuse multiply-adds differently
+            assert_close(part[1], full[1], "grad_grid without grad_input")
+            assert_close(part[2], full[2], "grad_grad_out without grad_input")
+    finally:
+        ops.force_path(0)
+
+
 @pytest.mark.parametrize("d,C", [(2, 16), (2, 4), (3, 8)])
 def test_autograd_chain_on_fast_paths_vs_composite(d, C):
     """Large enough for the fast paths (2D: tiled, 3D: channels-last + row scatter) to be chosen by the

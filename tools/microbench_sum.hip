@@ -1,0 +1,159 @@
+// Microbenchmarks for the sum-over-n ("PIXEL pattern") kernels: what does it cost when ONE lane walks all N
+// tables for its point (all 64 MiB of tables hot at once, instead of one 4 MiB table per launch phase), and
+// how fast are random row fetches from an array that fits the 256 MiB Infinity Cache but not the L2?
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench_sum tools/microbench_sum.hip && tools/microbench_sum
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x)                                                                        \
+    do {                                                                             \
+        hipError_t e_ = (x);                                                         \
+        if (e_ != hipSuccess) {                                                      \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                 \
+        }                                                                            \
+    } while (0)
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+// lane = point, loop over n: 4 nodes x 4 float4 per n (C = 16), position the same for all n (+ offset n/N)
+template <int NB>
+__global__ __launch_bounds__(256) void point_all_n(const float4 *table, int64_t nodes_per_n, int W, int n0, int64_t P,
+                                                   float *out) {
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    uint32_t h = hash32((uint32_t)p * 2654435761u + 17u);
+    float fx = (h & 0xffff) * (1.0f / 65536.0f) * (W - 2), fy = (h >> 16) * (1.0f / 65536.0f) * (W - 2);
+    float4 acc[4] = {};
+#pragma unroll 2
+    for (int k = 0; k < NB; ++k) {
+        int n = n0 + k;
+        float off = n * (1.0f / 16.0f);
+        int x = (int)(fx + off), y = (int)(fy + off);
+        const float4 *base = table + ((int64_t)n * nodes_per_n + (int64_t)y * W + x) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a = base[q], b = base[4 + q], c = base[(int64_t)W * 4 + q], d = base[(int64_t)W * 4 + 4 + q];
+            acc[q].x += a.x + b.x + c.x + d.x;
+            acc[q].y += a.y + b.y + c.y + d.y;
+            acc[q].z += a.z + b.z + c.z + d.z;
+            acc[q].w += a.w + b.w + c.w + d.w;
+        }
+    }
+    float r = 0.f;
+    for (int q = 0; q < 4; ++q) r += acc[q].x + acc[q].y + acc[q].z + acc[q].w;
+    if (r == -12345.f) out[0] = r;
+}
+
+// 4 lanes = one point (each lane one float4 of the channels), loop over n
+template <int NB>
+__global__ __launch_bounds__(256) void quad_all_n(const float4 *table, int64_t nodes_per_n, int W, int n0, int64_t P,
+                                                  float *out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t p = t >> 2;
+    int q = (int)(t & 3);
+    if (p >= P) return;
+    uint32_t h = hash32((uint32_t)p * 2654435761u + 17u);
+    float fx = (h & 0xffff) * (1.0f / 65536.0f) * (W - 2), fy = (h >> 16) * (1.0f / 65536.0f) * (W - 2);
+    float4 acc = {};
+#pragma unroll 4
+    for (int k = 0; k < NB; ++k) {
+        int n = n0 + k;
+        float off = n * (1.0f / 16.0f);
+        int x = (int)(fx + off), y = (int)(fy + off);
+        const float4 *base = table + ((int64_t)n * nodes_per_n + (int64_t)y * W + x) * 4 + q;
+        float4 a = base[0], b = base[4], c = base[(int64_t)W * 4], d = base[(int64_t)W * 4 + 4];
+        acc.x += a.x + b.x + c.x + d.x;
+        acc.y += a.y + b.y + c.y + d.y;
+        acc.z += a.z + b.z + c.z + d.z;
+        acc.w += a.w + b.w + c.w + d.w;
+    }
+    float r = acc.x + acc.y + acc.z + acc.w;
+    if (r == -12345.f) out[0] = r;
+}
+
+// one sample per lane-quad, table by table (what the shipped kernels do): sample s -> n = s / P
+__global__ __launch_bounds__(256) void quad_per_sample(const float4 *table, int64_t nodes_per_n, int W, int64_t P,
+                                                       int64_t S, float *out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t s = t >> 2;
+    int q = (int)(t & 3);
+    if (s >= S) return;
+    int n = (int)(s / P);
+    int64_t p = s - (int64_t)n * P;
+    uint32_t h = hash32((uint32_t)p * 2654435761u + 17u);
+    float fx = (h & 0xffff) * (1.0f / 65536.0f) * (W - 2), fy = (h >> 16) * (1.0f / 65536.0f) * (W - 2);
+    float off = n * (1.0f / 16.0f);
+    int x = (int)(fx + off), y = (int)(fy + off);
+    const float4 *base = table + ((int64_t)n * nodes_per_n + (int64_t)y * W + x) * 4 + q;
+    float4 a = base[0], b = base[4], c = base[(int64_t)W * 4], d = base[(int64_t)W * 4 + 4];
+    float r = a.x + b.y + c.z + d.w;
+    if (r == -12345.f) out[0] = r;
+}
+
+// walker-style fetch: 4 lanes fetch one row of R float4 (only the first 4+1 used), row id = random over `rows`
+// (rows * R * 16 bytes = the array size: 80 MiB fits the Infinity Cache, 1.25 GiB does not)
+template <int R>
+__global__ __launch_bounds__(256) void row_fetch(const float4 *src, uint32_t row_mask, int64_t fetches, float *out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int q = (int)(t & 3);
+    int64_t w = t >> 2;                       // walker id
+    const int64_t per = 16;                   // fetches per walker
+    float4 acc = {};
+    for (int64_t i = 0; i < per; ++i) {
+        int64_t j = w * per + i;
+        if (j >= fetches) break;
+        uint32_t r = hash32((uint32_t)j * 2654435761u + 99u) & row_mask;
+        const float4 *row = src + (int64_t)r * R;
+        float4 g = row[q], c = row[4];
+        acc.x += g.x * c.x; acc.y += g.y * c.y; acc.z += g.z * c.z; acc.w += g.w * c.w;
+    }
+    float r = acc.x + acc.y + acc.z + acc.w;
+    if (r == -12345.f) out[0] = r;
+}
+
+static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
+
+#define TIME(label, ...)                                                                    \
+    do {                                                                                    \
+        float best = 1e9f;                                                                  \
+        for (int rep = 0; rep < 4; ++rep) {                                                 \
+            CK(hipEventRecord(e0)); __VA_ARGS__; CK(hipEventRecord(e1));                    \
+            CK(hipEventSynchronize(e1));                                                    \
+            float ms = time_ms(e0, e1);                                                     \
+            if (rep && ms < best) best = ms;                                                \
+        }                                                                                   \
+        CK(hipGetLastError());                                                              \
+        printf("%-88s %.3f ms\n", label, best);                                             \
+    } while (0)
+
+int main() {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float *dout; CK(hipMalloc(&dout, 64));
+    const int W = 256, N = 16;
+    const int64_t nodes = (int64_t)W * W, P = 1 << 20, S = P * N;
+    float4 *table; CK(hipMalloc(&table, (size_t)N * nodes * 64 + 4096)); CK(hipMemset(table, 0, (size_t)N * nodes * 64));
+    TIME("S1 per-sample quads, table by table (shipped layout), 2^24 samples", (quad_per_sample<<<S * 4 / 256, 256>>>(table, nodes, W, P, S, dout)));
+    TIME("S2 lane=point, loop over all 16 tables", (point_all_n<16><<<P / 256, 256>>>(table, nodes, W, 0, P, dout)));
+    TIME("S3 quad=point, loop over all 16 tables", (quad_all_n<16><<<P * 4 / 256, 256>>>(table, nodes, W, 0, P, dout)));
+    TIME("S4 quad=point, 2 launches x 8 tables", ({ for (int g = 0; g < 2; ++g) quad_all_n<8><<<P * 4 / 256, 256>>>(table, nodes, W, g * 8, P, dout); }));
+    TIME("S5 quad=point, 4 launches x 4 tables", ({ for (int g = 0; g < 4; ++g) quad_all_n<4><<<P * 4 / 256, 256>>>(table, nodes, W, g * 4, P, dout); }));
+    TIME("S6 quad=point, 8 launches x 2 tables", ({ for (int g = 0; g < 8; ++g) quad_all_n<2><<<P * 4 / 256, 256>>>(table, nodes, W, g * 2, P, dout); }));
+    TIME("S7 quad=point, 16 launches x 1 table", ({ for (int g = 0; g < 16; ++g) quad_all_n<1><<<P * 4 / 256, 256>>>(table, nodes, W, g, P, dout); }));
+    TIME("S8 lane=point, 4 launches x 4 tables", ({ for (int g = 0; g < 4; ++g) point_all_n<4><<<P / 256, 256>>>(table, nodes, W, g * 4, P, dout); }));
+    // row fetches: 2^24 fetches of 80 B rows (R = 5 float4) / 96 B (R = 6)
+    float4 *rows; CK(hipMalloc(&rows, (size_t)(1 << 24) * 96)); CK(hipMemset(rows, 0, (size_t)(1 << 24) * 96));
+    const int64_t F = 1 << 24;
+    TIME("R1 2^24 fetches of 80 B rows, random over 2^24 rows (1.25 GiB, HBM)", (row_fetch<5><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 24) - 1, F, dout)));
+    TIME("R2 2^24 fetches of 80 B rows, random over 2^20 rows (80 MiB, Infinity Cache)", (row_fetch<5><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
+    TIME("R3 2^24 fetches of 80 B rows, random over 2^16 rows (5 MiB, ~L2)", (row_fetch<5><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 16) - 1, F, dout)));
+    TIME("R4 2^24 fetches of 128 B-stride rows, random over 2^20 rows (128 MiB)", (row_fetch<8><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
+    TIME("R5 2^24 fetches of 64 B-stride rows (G only + coef from next row), 2^20 rows (64 MiB)", (row_fetch<4><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
+    return 0;
+}
