@@ -12,7 +12,13 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_sz = ctypes.c_size_t
 
-# name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, workspace, bytes, stream
+class CotangentLayout(ctypes.Structure):
+    """cs_cotangent_layout (include/cosine_sampler.h): n-strides, in elements, of grad_output / grad_out_ggout."""
+    _fields_ = [("grad_output_stride_n", ctypes.c_int64), ("grad_out_ggout_stride_n", ctypes.c_int64)]
+
+
+# name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, [layout*, backward stages only],
+# input_cl, plan, workspace, bytes, stream
 _STAGES = {
     "forward": 4,
     "backward": 6,
@@ -24,7 +30,7 @@ EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_pack_
             "cs2d_plan_bytes", "cs2d_plan_build", "cs_debug_force_path"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES])
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 
@@ -66,7 +72,9 @@ def load():
         for stage, nptr in _STAGES.items():
             fn = getattr(lib, "cs%dd_%s" % (dim, stage))
             fn.restype = _c_int
-            fn.argtypes = [_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + [_c_f, _c_f, _c_f, _c_sz, _c_f]
+            layout = [] if stage == "forward" else [ctypes.POINTER(CotangentLayout)]
+            fn.argtypes = ([_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + layout
+                           + [_c_f, _c_f, _c_f, _c_sz, _c_f])
     _lib = lib
     return lib
 

@@ -49,6 +49,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.d.vol = D * H * W;
     pb.d.tab_ns = 1;          // gathers read the caller's NC[D]HW tensor unless a stage switches to a channels-last copy
     pb.d.tab_cs = pb.d.vol;
+    pb.d.go_ns = pb.d.ho_ns = C * P;   // contiguous cotangents unless the entry point is given a layout
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
@@ -624,6 +625,14 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
      * 2.88 vs 2.14 ms): they stay on the caller's tensor until they get float4 node loads. */           \
     const float *table_ = input;
 
+// n-strides of the channel-major cotangents (include/cosine_sampler.h, cs_cotangent_layout)
+#define CS_LAYOUT()                                                                                  \
+    if (layout) {                                                                                    \
+        if (layout->grad_output_stride_n < 0 || layout->grad_out_ggout_stride_n < 0) return CS_ERR_INVALID; \
+        pb.d.go_ns = layout->grad_output_stride_n;                                                   \
+        pb.d.ho_ns = layout->grad_out_ggout_stride_n;                                                \
+    }
+
 // zero-element tensors legitimately come with null data pointers
 #define CS_NEED(...)                                                            \
     if (pb.d.S > 0 && pb.d.C > 0 && any_null({__VA_ARGS__})) return CS_ERR_INVALID;
@@ -640,9 +649,10 @@ int cs2d_forward(const float *input, const float *grid, const float *offset, flo
 
 int cs2d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input, float *grad_grid, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                  int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                  int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout, const float *input_cl,
                   const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
+    CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
@@ -659,10 +669,11 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
 int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_grid, const float *input,
                            const float *grid, const float *grad_output, const float *offset, float *grad_input,
                            float *grad_grid, float *grad_grad_out, int64_t N, int64_t C, int64_t H, int64_t W,
-                           int64_t P, int padding_mode, int align_corners, int kernel, int multicell,
+                           int64_t P, int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
                            void *stream) {
     CS_PROBLEM(2, 1)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     if (tiled)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
@@ -682,9 +693,10 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out, int64_t N, int64_t C, int64_t H,
                                     int64_t W, int64_t P, int padding_mode, int align_corners, int kernel,
-                                    int multicell, const float *input_cl, const void *plan, void *workspace,
+                                    int multicell, const cs_cotangent_layout *layout, const float *input_cl, const void *plan, void *workspace,
                                     size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
@@ -703,9 +715,11 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
 int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
                    const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_input,
                    float *grad_grad_out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode,
-                   int align_corners, int kernel, int multicell, const float *input_cl, const void *plan,
+                   int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout,
+                   const float *input_cl, const void *plan,
                    void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
@@ -735,9 +749,10 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
 
 int cs3d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input, float *grad_grid, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W,
-                  int64_t P, int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                  int64_t P, int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout, const float *input_cl,
                   const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
+    CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, workspace,
@@ -754,10 +769,11 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
 int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_grid, const float *input,
                            const float *grid, const float *grad_output, const float *offset, float *grad_input,
                            float *grad_grid, float *grad_grad_out, int64_t N, int64_t C, int64_t D, int64_t H,
-                           int64_t W, int64_t P, int padding_mode, int align_corners, int kernel, int multicell,
+                           int64_t W, int64_t P, int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
                            void *stream) {
     CS_PROBLEM(3, D)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
@@ -777,9 +793,10 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out, int64_t N, int64_t C, int64_t D,
                                     int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners,
-                                    int kernel, int multicell, const float *input_cl, const void *plan,
+                                    int kernel, int multicell, const cs_cotangent_layout *layout, const float *input_cl, const void *plan,
                                     void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
@@ -798,9 +815,10 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
 int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
                    const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_input,
                    float *grad_grad_out, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                   int padding_mode, int align_corners, int kernel, int multicell, const float *input_cl,
+                   int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout, const float *input_cl,
                    const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(3, D)
+    CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,

@@ -29,6 +29,7 @@ struct Dims {
     // n*C*vol + node*tab_ns + c*tab_cs  -- (1, vol) for the caller's NC[D]HW tensor, (C, 1) for the
     // channels-last copy made by pack_channels_last (one node = one contiguous C-float row)
     int64_t tab_ns, tab_cs;
+    int64_t go_ns, ho_ns;   // elements between consecutive n of gOut / hO: C*P, or 0 for an n-broadcast (expanded) tensor
 };
 
 template <int DIM>
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void direct_backward(const float *__restrict__
 
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
     float *gi = grad_input ? grad_input + (int64_t)sm.n * d.C * d.vol : nullptr;
-    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
         float v[NC];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
     const float *ci = cI ? cI + (int64_t)sm.n * d.C * d.vol : nullptr;
     float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
-    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
     }
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
     float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
-    const float *go = gOut + (int64_t)sm.n * d.C * d.P + sm.p;
-    const float *ho = hO ? hO + (int64_t)sm.n * d.C * d.P + sm.p : nullptr;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+    const float *ho = hO ? hO + (int64_t)sm.n * d.ho_ns + sm.p : nullptr;
     float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
         cg[j] = (MODE >= 1 && cG) ? cG[so + j] : 0.0f;
         hg[j] = (MODE == 2 && hG) ? hG[so + j] : 0.0f;
     }
-    const float g = gOut[((int64_t)sm.n * d.C + c) * d.P + sm.p];
-    const float h = (MODE == 2 && hO) ? hO[((int64_t)sm.n * d.C + c) * d.P + sm.p] : 0.0f;
+    const float g = gOut[(int64_t)sm.n * d.go_ns + (int64_t)c * d.P + sm.p];
+    const float h = (MODE == 2 && hO) ? hO[(int64_t)sm.n * d.ho_ns + (int64_t)c * d.P + sm.p] : 0.0f;
     float *dst = acc_cl + (int64_t)sm.n * d.vol * d.C + c;
 #pragma unroll
     for (int a = 0; a < NC; ++a) {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
 #pragma unroll
     for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    const float *go = gOut + (int64_t)sm.n * C * d.P + sm.p;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float4 v[CQ][NC], g[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
-    const float *go = gOut + (int64_t)sm.n * C * d.P + sm.p;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float *ggo = ggOut + (int64_t)sm.n * C * d.P + sm.p;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
     sm.load<KERNEL, 1>(grid, offset, d, f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * C * d.P + sm.p, d.P, g);
+    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
     gather_nodes<CQ>(tab, sm, v);
     const float wy0 = sm.ax[1].w[0], wy1 = sm.ax[1].w[1], wx0 = sm.ax[0].w[0], wx1 = sm.ax[0].w[1];
     float gx = 0.f, gy = 0.f;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void point_backward_rows(const float *__restri
     Sample2 sm;
     sm.load<KERNEL, 1>(grid, offset, d, f);
     float4 g[CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * C * d.P + sm.p, d.P, g);
+    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
     put_payload<CQ>(row, g);
     *reinterpret_cast<float4 *>(row + C) = make_float4(sm.ax[0].w[0], sm.ax[0].w[1], sm.ax[1].w[0], sm.ax[1].w[1]);
     *reinterpret_cast<float4 *>(row + C + 4) = make_float4(sm.ax[0].d1, sm.ax[1].d1, 0.f, 0.f);
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * C * d.P + sm.p, d.P, g);
+    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
     gather_nodes<CQ>(tab, sm, v);
     float Dm[4], Sx[4], Sy[4];
 #pragma unroll
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
     float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * C * d.P + sm.p, d.P, g);
+    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
     gather_nodes<CQ>(tab, sm, v);
     float Dm[4], Em[4];
 #pragma unroll
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
     put_payload<CQ>(row, g);
     if (TWO) {
         float4 h[CQ];
-        load_stream<CQ>(hO + (int64_t)sm.n * C * d.P + sm.p, d.P, h);
+        load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h);
         put_payload<CQ>(row + C, h);
         *reinterpret_cast<float4 *>(row + 2 * C) = make_float4(Em[0], Em[1], Em[2], Em[3]);
         *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);

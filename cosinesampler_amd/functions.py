@@ -81,6 +81,12 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+# Cotangents of `output` (gOut, gOutggOut) are NOT forced contiguous: PIXEL sums the sampled features over n
+# (reference test_2d.py:51), so they arrive as `expand`ed (stride-0 along n) views of one (C,P) block and the
+# reference's `.contiguous()` (modules_2d.py:42,109) would write N*C*P floats per backward call only for the kernel
+# to read them back.  ops.keep_expanded leaves such views alone; the kernels take the n-stride.
+
+
 # dtypes: the kernels are fp32 (include/cosine_sampler.h).  The reference dispatches double/float/half
 # (2d.cu:905) but evaluates the blending weights and their derivatives in `float` whatever the tensor
 # type (2d.cu:239-261, :430-431), so float64/float16/bfloat16 tensors are served by
@@ -144,7 +150,7 @@ def _backward(ctx, grad_out):
     input, grid = ctx.saved_tensors
     if grad_out is None:
         return None, None, None, None, None, None
-    d_input, d_grid = _SamplerBackward.apply(input, grid, _c(grad_out), ctx.offset, ctx.cfg,
+    d_input, d_grid = _SamplerBackward.apply(input, grid, ops.keep_expanded(grad_out), ctx.offset, ctx.cfg,
                                              _engine_wants(ctx, 0), ctx.step)
     return d_input, d_grid, None, None, None, None
 
@@ -239,6 +245,6 @@ class _SamplerBackwardBackward(Function):
             return None, None, None, None, None, None, None, None, None
         cfg = ctx.cfg
         gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), _f32(_c(gOutgGrid)),
-                                      _f32(_c(gOutggOut)), ctx.offset, cfg.pad, cfg.align_corners, cfg.kernel,
+                                      _f32(ops.keep_expanded(gOutggOut)), ctx.offset, cfg.pad, cfg.align_corners, cfg.kernel,
                                       cfg.multicell, ctx=ctx.step)
         return _as(gInput, input), None, _as(ggOut, gOut), None, None, None, None, None, None

@@ -29,6 +29,31 @@ def _check(t, name, allow_none=False):
         raise RuntimeError("%s must be float32 (got %s): only the fp32 path is built" % (name, t.dtype))
 
 
+def _check_stream(t, name):
+    """A channel-major cotangent (N,C,[Do,]Ho,Wo): contiguous, or -- beyond the reference, which insists on
+    contiguous (2d.cpp:5) -- expanded along n (stride 0) over one contiguous (C,[Do,]Ho,Wo) block, which is what
+    the backward of PIXEL's `features.sum(0)` hands over.  -> the n-stride in elements."""
+    if t is None or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s): only the fp32 path is built" % (name, t.dtype))
+    if t.is_contiguous():
+        return t[0].numel() if t.shape[0] else 0
+    if t.dim() >= 2 and t.stride(0) == 0 and t[0].is_contiguous():
+        return 0
+    raise RuntimeError("%s must be contiguous (or expanded along n only)" % name)
+
+
+def keep_expanded(t):
+    """What the autograd layer does to an incoming cotangent instead of `.contiguous()`: leave an n-expanded
+    tensor alone (the kernels take its stride), make anything else contiguous."""
+    if t is None or t.is_contiguous():
+        return t
+    if t.dim() >= 2 and t.shape[0] > 1 and t.stride(0) == 0 and t[0].is_contiguous():
+        return t
+    return t.contiguous()
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -50,8 +75,14 @@ def _problem(input, grid):
     return dim, [int(s) for s in input.shape], P
 
 
-def _same(t, like_shape, name, device):
-    _check(t, name)
+def _same(t, like_shape, name, device, stream=False):
+    """-> n-stride in elements when `stream` (an n-expanded tensor is allowed), else None."""
+    ns = _check_stream(t, name) if stream else _check(t, name)
+    _shape_dev(t, like_shape, name, device)
+    return ns
+
+
+def _shape_dev(t, like_shape, name, device):
     if tuple(t.shape) != tuple(like_shape):
         raise RuntimeError("%s must have shape %s, got %s" % (name, tuple(like_shape), tuple(t.shape)))
     if t.device != device:
@@ -113,7 +144,7 @@ class StepContext(object):
 
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
-          grid=None, offset=None, want_plan=False, have_cI=False):
+          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None):
     if kernel not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), got %r" % (kernel,))
@@ -130,8 +161,13 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
         need = lib.cs_workspace_bytes(dim, _lib.STAGE_ID[stage], shape[0], shape[1], D, shape[-2], shape[-1], P,
                                       int(cl is not None), int(plan is not None), int(have_cI))
         ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
+        tail = (_ptr(cl), _ptr(plan), _ptr(ws), need, stream)
+        if stage != "forward":
+            CP = shape[1] * P
+            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns)
+            tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
-                _ptr(cl), _ptr(plan), _ptr(ws), need, stream)
+                *tail)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
 
 
@@ -159,12 +195,12 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     (the reference returns an undefined Tensor, 2d.cpp:73-79)."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
-    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     grad_input = torch.empty_like(input) if input_requires_grad else None
     grad_grid = torch.empty_like(grid)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
                             _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
-          ctx, input, grid, offset, want_plan=bool(input_requires_grad))
+          ctx, input, grid, offset, want_plan=bool(input_requires_grad), go_ns=go_ns)
     return grad_input, grad_grid
 
 
@@ -176,7 +212,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
     the scatter half of the stage, and the point plan it needs, are skipped."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
-    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     if input_requires_grad:
         _same(grad_out_input, input.shape, "grad_out_input", input.device)
     else:
@@ -185,12 +221,12 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     grad_input = torch.empty_like(input) if want_grad_input else None
     grad_grid = torch.empty_like(grid)
-    grad_grad_out = torch.empty_like(grad_output)
+    grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("backward_backward", dim,
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=want_grad_input, have_cI=grad_out_input is not None)
+          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -200,16 +236,16 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
     reference kernel (2d.cu:736)."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
-    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     _same(grad_out_ggrid, grid.shape, "grad_out_ggrid", input.device)
     grad_input = torch.empty_like(input)
-    grad_grad_out = torch.empty_like(grad_output)
+    grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("backward_backward_backward", dim,
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True)
+          want_plan=True, go_ns=go_ns)
     return grad_input, grad_grad_out
 
 
@@ -220,17 +256,18 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
     grad_out_grid / grad_out_ggrid / grad_out_ggout may each be None (= zeros)."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
-    _same(grad_output, out_shape(input, grid), "grad_output", input.device)
+    go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
         if t is not None:
             _same(t, grid.shape, nm, input.device)
+    ho_ns = None
     if grad_out_ggout is not None:
-        _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device)
+        ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
     grad_input = torch.empty_like(input)
-    grad_grad_out = torch.empty_like(grad_output)
+    grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("bbb_fused", dim,
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True)
+          want_plan=True, go_ns=go_ns, ho_ns=ho_ns)
     return grad_input, grad_grad_out

@@ -47,13 +47,24 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 3
+#define CS_ABI_VERSION 4
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
 enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
+
+/* How the channel-major cotangents of a backward stage lie in memory.  The reference demands contiguous
+ * (N,C,[Do,]Ho,Wo) tensors (CHECK_CONTIGUOUS, 2d.cpp:5), so PIXEL-style callers, which sum the sampled features
+ * over n before the MLP, pay a 4*N*C*P-byte `.contiguous()` copy of an *expanded* gradient on every backward
+ * call.  Here the n-stride of those tensors is a parameter: 0 = one (C,P) block shared by every n (what
+ * `Tensor.expand` produces), C*P = contiguous; within one n the block is always contiguous (C,P).
+ * A NULL layout pointer means contiguous. */
+typedef struct cs_cotangent_layout {
+    int64_t grad_output_stride_n;      /* elements between consecutive n of grad_output */
+    int64_t grad_out_ggout_stride_n;   /* same for grad_out_ggout (cs*_bbb_fused only) */
+} cs_cotangent_layout;
 
 int cs_abi_version(void);
 const char *cs_error_string(int code);
@@ -97,7 +108,7 @@ int cs2d_forward(const float *input, const float *grid, const float *offset, flo
 int cs2d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input /* nullable */, float *grad_grid,
                   int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                  int padding_mode, int align_corners, int kernel, int multicell,
+                  int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                   const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces `_cosine_2d.backward_backward` (2d.cpp:87-106 -> 2d.cu:990).
@@ -109,7 +120,7 @@ int cs2d_backward_backward(const float *grad_out_input /* nullable */, const flo
                            const float *input, const float *grid, const float *grad_output, const float *offset,
                            float *grad_input /* nullable */, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                           int padding_mode, int align_corners, int kernel, int multicell,
+                           int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces `_cosine_2d.backward_backward_backward` (2d.cpp:108-127 -> 2d.cu:1058). */
@@ -117,7 +128,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out,
                                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                                    int padding_mode, int align_corners, int kernel, int multicell,
+                                    int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                                     const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The whole of CosineSamplerBackwardBackward.backward (modules_2d.py:98-111) in one pass: the
@@ -131,7 +142,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    const float *grad_out_ggout /* nullable */, const float *offset,
                    float *grad_input, float *grad_grad_out,
                    int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                   int padding_mode, int align_corners, int kernel, int multicell,
+                   int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                    const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- 3D: same contracts; 3d.cpp:50-131 -> 3d.cu:1073,1115,1167,1241; modules_3d.py:87-100 --- */
@@ -144,21 +155,21 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
 int cs3d_backward(const float *grad_output, const float *input, const float *grid, const float *offset,
                   float *grad_input /* nullable */, float *grad_grid,
                   int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                  int padding_mode, int align_corners, int kernel, int multicell,
+                  int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                   const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_backward_backward(const float *grad_out_input /* nullable */, const float *grad_out_grid /* nullable */,
                            const float *input, const float *grid, const float *grad_output, const float *offset,
                            float *grad_input /* nullable */, float *grad_grid, float *grad_grad_out,
                            int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                           int padding_mode, int align_corners, int kernel, int multicell,
+                           int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_backward_backward_backward(const float *input, const float *grid, const float *grad_output,
                                     const float *grad_out_grid, const float *grad_out_ggrid, const float *offset,
                                     float *grad_input, float *grad_grad_out,
                                     int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                                    int padding_mode, int align_corners, int kernel, int multicell,
+                                    int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                                     const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_output,
@@ -166,7 +177,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    const float *grad_out_ggout /* nullable */, const float *offset,
                    float *grad_input, float *grad_grad_out,
                    int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                   int padding_mode, int align_corners, int kernel, int multicell,
+                   int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                    const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

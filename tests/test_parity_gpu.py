@@ -186,6 +186,46 @@ def test_second_backward_without_table_gradient(d, C, force, with_cI):
         ops.force_path(0)
 
 
+@pytest.mark.parametrize("d,C,force", [(2, 16, 2), (2, 8, 2), (2, 3, 0), (2, 32, 2), (3, 8, 2), (3, 5, 0), (3, 2, 2)])
+def test_expanded_cotangents_equal_contiguous_ones(d, C, force):
+    """cs_cotangent_layout: grad_output / grad_out_ggout expanded along n (stride 0, what the backward of PIXEL's
+    sum over n produces) must give what their `.contiguous()` copies give, in every stage, on every path."""
+    N, P = 3, 2500
+    sp = (37, 50) if d == 2 else (6, 9, 7)
+    t = _case(d, N, C, sp, P, seed=9900 + C, spread=1.15)
+    off = offsets(N, True).to(DEV)
+    inp, grid, cI, cG, hG = (_g(t[k]) for k in ("inp", "grid", "cI", "cG", "hG"))
+    gO_e = _g(t["gOut"])[:1].expand(N, *t["gOut"].shape[1:])
+    hO_e = _g(t["hO"])[1:2].expand(N, *t["hO"].shape[1:])
+    assert gO_e.stride(0) == 0 and not gO_e.is_contiguous()
+    gO_c, hO_c = gO_e.contiguous(), hO_e.contiguous()
+    ops.force_path(force)
+    try:
+        for shared in (False, True):
+            res = []
+            for gO, hO in ((gO_e, hO_e), (gO_c, hO_c)):
+                step = ops.StepContext() if shared else None
+                r = list(ops.backward(gO, inp, grid, off, 0, True, True, 0, True, ctx=step))
+                r += list(ops.backward(gO, inp, grid, off, 0, True, False, 0, True, ctx=step))[1:]
+                r += list(ops.backward_backward(cI, cG, inp, grid, gO, off, 0, True, True, 0, True, ctx=step))
+                r += list(ops.backward_backward(None, cG, inp, grid, gO, off, 0, True, False, 0, True, ctx=step,
+                                                want_grad_input=False))[1:]
+                r += list(ops.backward_backward_backward(inp, grid, gO, cG, hG, off, 0, True, True, 0, True, ctx=step))
+                r += list(ops.bbb_fused(inp, grid, gO, cG, hG, hO, off, 0, True, 0, True, ctx=step))
+                r += list(ops.bbb_fused(inp, grid, gO, cG, hG, None, off, 0, True, 0, True, ctx=step))
+                res.append(r)
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(*res)):
+                assert a.is_contiguous() and a.shape == b.shape
+                # same kernels, same values: equal up to the run-to-run order of scattered sums (grad_input) and
+                # of the plan's within-cell order (grad_grid from the tile walkers): last-bit differences only
+                assert_close(a, b, "output %d, expanded vs contiguous cotangents" % i, tol=2e-6)
+    finally:
+        ops.force_path(0)
+    with pytest.raises(RuntimeError):     # any other non-contiguous layout is still refused
+        ops.backward(gO_c.transpose(0, 1).contiguous().transpose(0, 1), inp, grid, off, 0, True, True, 0, True)
+
+
 @pytest.mark.parametrize("d,C", [(2, 16), (2, 4), (3, 8)])
 def test_autograd_chain_on_fast_paths_vs_composite(d, C):
     """Large enough for the fast paths (2D: tiled, 3D: channels-last + row scatter) to be chosen by the
