@@ -336,7 +336,8 @@ size_t fat_lds(int C, bool two) {
     size_t need = (size_t)256 * (two ? 2 * C + 8 : C + 4) * 4;
     return two ? std::max(need, (size_t)56 * 1024) : need;
 }   // 4 waves x 64 fat rows
-size_t point_lds() { return (size_t)4 * tl::REC_FLOATS * 4; }   // one geometry record block per wave
+// per wave: one geometry record block + the [C][64] result tile of point_forward
+size_t point_lds(int C) { return (size_t)4 * (tl::REC_FLOATS + C * tl::OUT_LD) * 4; }
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
                   const float *input_cl, void *workspace, size_t workspace_bytes) {
@@ -344,7 +345,7 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds(), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds(pb.d.C), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
     return launch_status();
 }

@@ -262,6 +262,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 enum { R_NODE = 0, R_WX0 = 4, R_WX1, R_WY0, R_WY1, R_FIELDS };
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 constexpr int REC_FLOATS = R_FIELDS * 64;   // per wave
+constexpr int OUT_LD = 68;                  // row pitch of the result tile: channel quads land 16 banks apart
 
 // phase 1 of point_forward: lane = sample; everything phase 2 needs goes to `rec`
 template <int KERNEL>
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     const int n = blockIdx.y;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
     float *obase = out + (int64_t)n * C * d.P;
+    float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
         QuadSample qs;
@@ -355,7 +357,19 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
         float4 acc = zero4();
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc = fma4(qs.W[a], v[a], acc);
-        if (qs.live) store_quad(obase + (int64_t)(4 * qs.q) * d.P + qs.p, d.P, acc);
+        // results go back to lane = sample through LDS: 256 contiguous bytes per store instruction instead of
+        // four 64-byte segments (measured: forward 0.70 -> 0.51 ms; the stores alone cost 0.34 ms the other way)
+        ot[(4 * qs.q + 0) * OUT_LD + qs.sl] = acc.x;
+        ot[(4 * qs.q + 1) * OUT_LD + qs.sl] = acc.y;
+        ot[(4 * qs.q + 2) * OUT_LD + qs.sl] = acc.z;
+        ot[(4 * qs.q + 3) * OUT_LD + qs.sl] = acc.w;
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < d.P) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int c = 0; c < C; ++c) st_stream_wt(obase + (int64_t)c * d.P + p, ot[c * OUT_LD + lane]);
     }
 }
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B harness for kernel experiments.  HERE (no GPU):  tools/ab.sh build NAME "-DFLAG ..."   builds
+# cosinesampler_amd/lib/alt_NAME.so from the working tree with extra flags (the .so travels with gpurun).
+# ON THE GPU BOX:  tools/ab.sh run NAME [NAME...]   prints bench stage times for the default library and each variant.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+if [ "$1" = build ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function $3 \
+      -o $R/cosinesampler_amd/lib/alt_$2.so $R/cosinesampler_amd/csrc/cs_abi.hip
+  echo built alt_$2.so
+elif [ "$1" = run ]; then
+  shift
+  for v in default "$@"; do
+    if [ $v = default ]; then unset COSINESAMPLER_LIB; else export COSINESAMPLER_LIB=$R/cosinesampler_amd/lib/alt_$v.so; fi
+    python $R/bench.py --no-cpu-baseline --no-helmholtz --steps 10 --warmup 2 > /tmp/ab_$v.json
+    python - $v /tmp/ab_$v.json <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+print("%-16s step %.3f ms | " % (sys.argv[1], j["ms_per_step"]) + "  ".join("%s %.3f" % (k[:9], v) for k, v in j["stages_ms"].items()), flush=True)
+PY
+  done
+fi
