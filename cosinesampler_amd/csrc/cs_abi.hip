@@ -329,14 +329,9 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
 
 dim3 point_grid(const Problem &pb) { return dim3((unsigned)((pb.d.P + kBlock - 1) / kBlock), (unsigned)pb.d.N); }
 
-// 4 waves x 64 fat rows.  The two-payload third-backward kernel is given 56 KiB whatever it needs: that
-// caps it at 2 resident workgroups per CU, which measured 5 % faster than the 4 its registers allow
-// (fewer concurrent streams fighting the table slice for the L2); the one-payload kernels showed no such gain.
-size_t fat_lds(int C, bool two) {
-    size_t need = (size_t)256 * (two ? 2 * C + 8 : C + 4) * 4;
-    return two ? std::max(need, (size_t)56 * 1024) : need;
-}   // 4 waves x 64 fat rows
-// per wave: one geometry record block + the [C][64] result tile of point_forward
+// three-phase point kernels: per wave 64 fat rows + the node/result record (+ the coefficient record of point_bb)
+size_t q_lds(int stride, bool co) { return (size_t)4 * (64 * stride + tl::QREC + (co ? 12 * 64 : 0)) * 4; }
+// point_forward, per wave: one geometry record block + the [C][64] result tile
 size_t point_lds(int C) { return (size_t)4 * (tl::REC_FLOATS + C * tl::OUT_LD) * 4; }
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
@@ -359,8 +354,8 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
-                                          gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, false), pb.stream>>>(
+                                          gOut, pr.icl, grid, offset, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
     // with grad_input: streams -> fat rows (no gathers), then the tile walkers produce grad_input AND grad_grid
@@ -402,21 +397,22 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
+    const size_t shm = q_lds(pb.d.C + 4, true);
     if (!gInput) {
         if (cIcl) {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                               cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
         } else {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, 0, pb.stream>>>(
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                               cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
         }
         return launch_status();
     }
     if (cIcl) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                           cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                           cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     }
     rc = launch_status();
@@ -436,17 +432,18 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (hO) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, fat_lds(pb.d.C, true), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * pb.d.C + 8, false), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
+    } else {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, false), pb.stream>>>(
+                                          pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
+        rc = launch_status();
+        if (rc) return rc;
+        return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
     }
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, fat_lds(pb.d.C, false), pb.stream>>>(
-                                      pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
-    rc = launch_status();
-    if (rc) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,8 +12,8 @@
 //   plan   (once per grid)  sort the samples by (n, 16x16-cell tile, cell): `sorted[j]` = sample id
 //                           at sorted position j, first position of every tile (`tile_begin`) and
 //                           of every cell in it (`cell_begin`).
-//   point kernel (p-order)  one lane per sample, every stream access coalesced, node vectors
-//                           gathered from the channels-last copy of `input`; computes every
+//   point kernel (p-order)  every stream access coalesced (lane = sample), node vectors gathered from the
+//                           channels-last copy of `input` (C/4 lanes per sample); computes every
 //                           p-ordered output (grad_grid / ggOut / ...) and leaves, per sample, one
 //                           contiguous "fat row" in p-order: the C cotangent values followed by the
 //                           4 node coefficients (third backward: two of each).  Sequential writes.
@@ -218,12 +218,13 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
 
 // ------------------------------------------------------------------------------------------------
 // point kernels.  Launch: grid (ceil(P/256), N), 256 threads; a wave owns 64 consecutive points of
-// one n.  point_forward works in two phases per wave:
-//   1. lane = sample: coordinates and weights  ->  a small record in LDS;
-//   2. lane = (sample, channel quad): CQ = C/4 lanes share a sample, so one wave instruction
-//      fetches 64/CQ whole 16*CQ-byte node rows (the L1 sees each node line once, not CQ times).
-// The backward point kernels keep lane = sample throughout: their extra stream (gOut) is read as
-// 256 contiguous bytes per wave per channel, which measured faster than 64-byte segments.
+// one n.  Every point kernel alternates between two lane layouts, exchanging data through the wave's LDS:
+//   lane = sample                   for everything p-ordered: coordinates and weights, the channel-major
+//                                   streams (256 contiguous bytes per wave instruction; 64-byte segments
+//                                   measured 45 % slower), the fat rows;
+//   lane = (sample, channel quad)   for the node gathers: CQ = C/4 lanes share a sample, one wave instruction
+//                                   fetches 64/CQ whole node rows with 4 float4 registers per lane instead of
+//                                   16, so many more requests are in flight per SIMD.
 // ------------------------------------------------------------------------------------------------
 // Stream accesses (each element touched once per kernel) are marked nontemporal so that they do
 // not displace the feature table from L2 / Infinity Cache.
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     }
 }
 
-// ---- backward point kernels: lane = sample (every stream access is 256 contiguous bytes per wave) ----
+// ---- backward point kernels: what a lane = sample phase knows about its sample ----
 struct Sample2 {
     int n;
     int64_t p, s;
@@ -411,33 +412,8 @@ struct Sample2 {
     }
 };
 
-// all 4*CQ node vectors of a sample; zero-padded nodes read node 0 and are masked afterwards
-template <int CQ>
-__device__ __forceinline__ void gather_nodes(const float4 *tab, const Sample2 &sm, float4 (&v)[4][CQ]) {
-#ifdef CS_DBG_NO_GATHER
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < CQ; ++q) v[a][q] = make_float4(sm.W[a], sm.W[a] + q, 1.f, 2.f);
-    return;
-#endif
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < CQ; ++q) v[a][q] = tab[(sm.node[a] == NO_NODE ? 0u : sm.node[a]) * CQ + q];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < CQ; ++q)
-            if (sm.node[a] == NO_NODE) v[a][q] = zero4();
-}
 template <int CQ>
 __device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 (&g)[CQ]) {
-#ifdef CS_DBG_NO_GLOAD
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) g[q] = make_float4((float)P, (float)q, 1.f, 2.f);
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < CQ; ++q) g[q] = load_quad(src + (int64_t)(4 * q) * P, P);
 }
@@ -477,38 +453,6 @@ __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n
     }
 }
 
-template <int KERNEL, int CQ>
-__global__ __launch_bounds__(256) void point_backward(const float *__restrict__ gOut, const float *__restrict__ icl,
-                                                      const float *__restrict__ grid, const float *__restrict__ offset,
-                                                      float *__restrict__ fat, float *__restrict__ grad_grid,
-                                                      Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 4;
-    Sample2 sm;
-    sm.load<KERNEL, 1>(grid, offset, d, f);
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
-    gather_nodes<CQ>(tab, sm, v);
-    const float wy0 = sm.ax[1].w[0], wy1 = sm.ax[1].w[1], wx0 = sm.ax[0].w[0], wx1 = sm.ax[0].w[1];
-    float gx = 0.f, gy = 0.f;
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        float d0 = dot4(v[0][q], g[q]), d1 = dot4(v[1][q], g[q]), d2 = dot4(v[2][q], g[q]), d3 = dot4(v[3][q], g[q]);
-        gx += wy0 * (d1 - d0) + wy1 * (d3 - d2);
-        gy += wx0 * (d2 - d0) + wx1 * (d3 - d1);
-    }
-    if (sm.live) *reinterpret_cast<float2 *>(grad_grid + sm.s * 2) = make_float2(sm.ax[0].d1 * gx, sm.ax[1].d1 * gy);
-    if (fat) {
-        extern __shared__ float lds[];
-        float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
-        float *row = stage + (threadIdx.x & 63) * STRIDE;
-        put_payload<CQ>(row, g);
-        *reinterpret_cast<float4 *>(row + C) = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
-        __syncthreads();
-        flush_rows<STRIDE>(stage, fat, sm.n, d);
-    }
-}
-
 // First backward when grad_input is wanted: NO gathers here.  The point kernel only turns the p-ordered
 // streams into fat rows [gOut(C) | wx0 wx1 wy0 wy1 | d1x d1y 0 0]; the tile kernel, which visits the
 // samples cell by cell and therefore has the 4 node rows of the current cell in registers for free,
@@ -533,115 +477,232 @@ __global__ __launch_bounds__(256) void point_backward_rows(const float *__restri
     flush_rows<STRIDE>(stage, fat, sm.n, d);
 }
 
-// second backward, point part.  cIcl = channels-last copy of gOutInput (HAS_CI).
-// WANT_ROWS = false: the caller has no use for grad_input, no fat rows are left behind.  (A template flag, not
-// a run-time test of `fat`: the early exit changes the register allocation of the full kernel -- 117 VGPRs /
-// 4 waves per SIMD instead of 136 / 3 -- and that version measured 9 % slower.)
-template <int KERNEL, int CQ, bool HAS_CI, bool WANT_ROWS = true>
-__global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, const float *__restrict__ cG,
-                                                const float *__restrict__ icl, const float *__restrict__ grid,
-                                                const float *__restrict__ gOut, const float *__restrict__ offset,
-                                                float *__restrict__ fat, float *__restrict__ gGrid,
-                                                float *__restrict__ ggOut, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 4;
-    Sample2 sm;
-    sm.load<KERNEL, 2>(grid, offset, d, f);
-    float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
-    gather_nodes<CQ>(tab, sm, v);
-    float Dm[4], Sx[4], Sy[4];
+// ------------------------------------------------------------------------------------------------
+// Three-phase point kernels.  (Their first version kept lane = sample throughout: 16 float4 gathers per lane
+// cost 64 VGPRs, 136 in total, 3 waves per SIMD, and the gathers alone took 0.67 ms against 0.29 ms with CQ
+// lanes per sample -- an ablation with -D switches, profiles/round1_ablation.txt.)
+//   phase 1  lane = sample   geometry, coalesced stream loads; the fat row [payload | coefficients] is built in
+//                            the wave's LDS stage, node ids go to `rec`; the rows are flushed to HBM
+//   phase 2  CQ lanes = one sample (lane q owns channels 4q..4q+3), 64/CQ samples per pass: 4 float4 gathers
+//                            per lane, all passes in flight; cotangent quad read back from the stage row, per
+//                            channel results written over it, per sample dot products reduced by shuffles
+//   phase 3  lane = sample   results leave as 256 contiguous bytes per store instruction
+// ------------------------------------------------------------------------------------------------
+constexpr int QREC = 6 * 64;   // per wave: node[4] (uint), then two floats per sample for phase 2 -> 3 results
+
+__device__ __forceinline__ void q_put_nodes(float *rec, const Sample2 &sm) {
+    uint32_t *ru = reinterpret_cast<uint32_t *>(rec);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
-        Sx[a] = sm.pure2(a, 0) * cg.x;   // 2D: pure second derivatives only (2d.cu:705-706)
-        Sy[a] = sm.pure2(a, 1) * cg.y;
-    }
+    for (int a = 0; a < 4; ++a) ru[a * 64 + lane] = sm.node[a];
+}
+template <int CQ>
+__device__ __forceinline__ void q_gather(const float4 *tab, const float *rec, int sl, int q, float4 (&v)[4]) {
+    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
+    uint32_t node[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) node[a] = ru[a * 64 + sl];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = tab[(node[a] == NO_NODE ? 0u : node[a]) * CQ + q];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (node[a] == NO_NODE) v[a] = zero4();
+}
+// sum over the CQ lanes of a sample (CQ in {1,2,4}: lanes of one sample are adjacent)
+template <int CQ>
+__device__ __forceinline__ float q_reduce(float x) {
+    if (CQ >= 2) x += __shfl_xor(x, 1);
+    if (CQ >= 4) x += __shfl_xor(x, 2);
+    return x;
+}
+template <int CQ>
+__device__ __forceinline__ void q_store_rows(const float *stage, int stride, float *dst, int64_t P, bool live) {
+    if (!live) return;
+    const float *row = stage + (threadIdx.x & 63) * stride;
     float4 o[CQ];
-    float sx = 0.f, sy = 0.f;
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        float4 acc = zero4(), tx = zero4(), ty = zero4();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            acc = fma4(Dm[a], v[a][q], acc);
-            tx = fma4(Sx[a], v[a][q], tx);
-            ty = fma4(Sy[a], v[a][q], ty);
-        }
-        sx += dot4(tx, g[q]);
-        sy += dot4(ty, g[q]);
-        o[q] = acc;
-    }
-    if (HAS_CI) {   // + sum_a gOutInput[q_a] * W_a   (2d.cu:694-697)
-        const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
-        float4 u[4][CQ];
-        gather_nodes<CQ>(ctab, sm, u);
-#pragma unroll
-        for (int q = 0; q < CQ; ++q)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) o[q] = fma4(sm.W[a], u[a][q], o[q]);
-    }
-    if (sm.live) {
-        store_stream<CQ>(ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
-        *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(sx, sy);
-    }
-    if (!WANT_ROWS) return;
-    extern __shared__ float lds[];
-    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
-    float *row = stage + (threadIdx.x & 63) * STRIDE;
-    put_payload<CQ>(row, g);
-    *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
-    __syncthreads();
-    flush_rows<STRIDE>(stage, fat, sm.n, d);
+    for (int q = 0; q < CQ; ++q) o[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+    store_stream<CQ>(dst, P, o);
 }
 
-// fused third backward, point part.  Fat row: TWO ? [gOut | hO | E | D] : [gOut | E]
-template <int KERNEL, int CQ, bool TWO>
-__global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, const float *__restrict__ grid,
-                                                 const float *__restrict__ gOut, const float *__restrict__ cG,
-                                                 const float *__restrict__ hG, const float *__restrict__ hO,
-                                                 const float *__restrict__ offset, float *__restrict__ fat,
-                                                 float *__restrict__ ggOut, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = TWO ? 2 * C + 8 : C + 4;
-    Sample2 sm;
-    sm.load<KERNEL, 2>(grid, offset, d, f);
-    float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
-    float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float4 g[CQ], v[4][CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
-    gather_nodes<CQ>(tab, sm, v);
-    float Dm[4], Em[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
-        Em[a] = sm.pure2(a, 0) * (hg.x * cg.x) + sm.pure2(a, 1) * (hg.y * cg.y);   // 2d.cu:876
-    }
-    float4 o[CQ];
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        float4 acc = zero4();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc = fma4(Em[a], v[a][q], acc);
-        o[q] = acc;
-    }
-    if (sm.live) store_stream<CQ>(ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, o);
+// first backward without grad_input: grad_grid only.  LDS stage: [64][C+4] = g | wx0 wx1 wy0 wy1
+template <int KERNEL, int CQ>
+__global__ __launch_bounds__(256) void point_backward(const float *__restrict__ gOut, const float *__restrict__ icl,
+                                                        const float *__restrict__ grid, const float *__restrict__ offset,
+                                                        float *__restrict__ grad_grid, Dims d, Flags f) {
+    constexpr int C = 4 * CQ, STRIDE = C + 4;
     extern __shared__ float lds[];
-    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
-    float *row = stage + (threadIdx.x & 63) * STRIDE;
-    put_payload<CQ>(row, g);
-    if (TWO) {
-        float4 h[CQ];
-        load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h);
-        put_payload<CQ>(row + C, h);
-        *reinterpret_cast<float4 *>(row + 2 * C) = make_float4(Em[0], Em[1], Em[2], Em[3]);
-        *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
-    } else {
-        *reinterpret_cast<float4 *>(row + C) = make_float4(Em[0], Em[1], Em[2], Em[3]);
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC);
+    float *rec = stage + 64 * STRIDE;
+    const int lane = threadIdx.x & 63;
+    Sample2 sm;
+    sm.load<KERNEL, 1>(grid, offset, d, f);
+    {
+        float4 g[CQ];
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        float *row = stage + lane * STRIDE;
+        put_payload<CQ>(row, g);
+        *reinterpret_cast<float4 *>(row + C) = make_float4(sm.ax[0].w[0], sm.ax[0].w[1], sm.ax[1].w[0], sm.ax[1].w[1]);
+        q_put_nodes(rec, sm);
     }
     __syncthreads();
-    flush_rows<STRIDE>(stage, fat, sm.n, d);
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const int q = lane % CQ;
+    float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) {
+        const int sl = sub * (64 / CQ) + lane / CQ;
+        const float4(&v)[4] = vv[sub];
+        const float *row = stage + sl * STRIDE;
+        const float4 g4 = *reinterpret_cast<const float4 *>(row + 4 * q);
+        const float4 w = *reinterpret_cast<const float4 *>(row + C);   // wx0 wx1 wy0 wy1
+        float d0 = dot4(v[0], g4), d1 = dot4(v[1], g4), d2 = dot4(v[2], g4), d3 = dot4(v[3], g4);
+        float gx = q_reduce<CQ>(w.z * (d1 - d0) + w.w * (d3 - d2));
+        float gy = q_reduce<CQ>(w.x * (d2 - d0) + w.y * (d3 - d1));
+        if (q == 0) {
+            rec[4 * 64 + sl] = gx;
+            rec[5 * 64 + sl] = gy;
+        }
+    }
+    __syncthreads();
+    if (sm.live)
+        *reinterpret_cast<float2 *>(grad_grid + sm.s * 2) =
+            make_float2(sm.ax[0].d1 * rec[4 * 64 + lane], sm.ax[1].d1 * rec[5 * 64 + lane]);
+}
+
+// second backward.  LDS stage row: g | Dm[4] (the fat row) and, in `rec`, node ids; the per sample coefficient
+// sets Sx, Sy (and W for HAS_CI) live in a second record block `co`: [12][64]
+template <int KERNEL, int CQ, bool HAS_CI, bool WANT_ROWS>
+__global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, const float *__restrict__ cG,
+                                                  const float *__restrict__ icl, const float *__restrict__ grid,
+                                                  const float *__restrict__ gOut, const float *__restrict__ offset,
+                                                  float *__restrict__ fat, float *__restrict__ gGrid,
+                                                  float *__restrict__ ggOut, Dims d, Flags f) {
+    constexpr int C = 4 * CQ, STRIDE = C + 4, CO = 12 * 64;
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC + CO);
+    float *rec = stage + 64 * STRIDE;
+    float *co = rec + QREC;
+    const int lane = threadIdx.x & 63;
+    Sample2 sm;
+    sm.load<KERNEL, 2>(grid, offset, d, f);
+    {
+        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
+        float4 g[CQ];
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        float *row = stage + lane * STRIDE;
+        put_payload<CQ>(row, g);
+        float Dm[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
+            co[a * 64 + lane] = sm.pure2(a, 0) * cg.x;         // Sx: 2D keeps pure second derivatives only (2d.cu:705-706)
+            co[(4 + a) * 64 + lane] = sm.pure2(a, 1) * cg.y;   // Sy
+            if (HAS_CI) co[(8 + a) * 64 + lane] = sm.W[a];
+        }
+        *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
+        q_put_nodes(rec, sm);
+    }
+    __syncthreads();
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const float4 *ctab = HAS_CI ? reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C) : nullptr;
+    const int q = lane % CQ;
+    float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    if (WANT_ROWS) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) {
+        const int sl = sub * (64 / CQ) + lane / CQ;
+        const float4(&v)[4] = vv[sub];
+        float *row = stage + sl * STRIDE;
+        const float4 g4 = *reinterpret_cast<const float4 *>(row + 4 * q);
+        const float4 Dm = *reinterpret_cast<const float4 *>(row + C);
+        float4 acc = zero4(), tx = zero4(), ty = zero4();
+        const float dm[4] = {Dm.x, Dm.y, Dm.z, Dm.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            acc = fma4(dm[a], v[a], acc);
+            tx = fma4(co[a * 64 + sl], v[a], tx);
+            ty = fma4(co[(4 + a) * 64 + sl], v[a], ty);
+        }
+        if (HAS_CI) {   // + sum_a gOutInput[q_a] * W_a   (2d.cu:694-697)
+            float4 u[4];
+            q_gather<CQ>(ctab, rec, sl, q, u);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc = fma4(co[(8 + a) * 64 + sl], u[a], acc);
+        }
+        float sx = q_reduce<CQ>(dot4(tx, g4)), sy = q_reduce<CQ>(dot4(ty, g4));
+        *reinterpret_cast<float4 *>(row + 4 * q) = acc;   // over the cotangent quad this lane just consumed
+        if (q == 0) {
+            rec[4 * 64 + sl] = sx;
+            rec[5 * 64 + sl] = sy;
+        }
+    }
+    __syncthreads();
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, sm.live);
+    if (sm.live) *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(rec[4 * 64 + lane], rec[5 * 64 + lane]);
+}
+
+// fused third backward.  Stage row = the fat row: TWO ? [gOut | hO | E | D] : [gOut | E]
+template <int KERNEL, int CQ, bool TWO>
+__global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, const float *__restrict__ grid,
+                                                   const float *__restrict__ gOut, const float *__restrict__ cG,
+                                                   const float *__restrict__ hG, const float *__restrict__ hO,
+                                                   const float *__restrict__ offset, float *__restrict__ fat,
+                                                   float *__restrict__ ggOut, Dims d, Flags f) {
+    constexpr int C = 4 * CQ, STRIDE = TWO ? 2 * C + 8 : C + 4, EOFF = TWO ? 2 * C : C;
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC);
+    float *rec = stage + 64 * STRIDE;
+    const int lane = threadIdx.x & 63;
+    Sample2 sm;
+    sm.load<KERNEL, 2>(grid, offset, d, f);
+    {
+        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
+        float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
+        float Dm[4], Em[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
+            Em[a] = sm.pure2(a, 0) * (hg.x * cg.x) + sm.pure2(a, 1) * (hg.y * cg.y);   // 2d.cu:876
+        }
+        float *row = stage + lane * STRIDE;
+        float4 g[CQ];
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        put_payload<CQ>(row, g);
+        if (TWO) {
+            float4 h[CQ];
+            load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h);
+            put_payload<CQ>(row + C, h);
+            *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
+        }
+        *reinterpret_cast<float4 *>(row + EOFF) = make_float4(Em[0], Em[1], Em[2], Em[3]);
+        q_put_nodes(rec, sm);
+    }
+    __syncthreads();
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const int q = lane % CQ;
+    float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) {
+        const int sl = sub * (64 / CQ) + lane / CQ;
+        const float4(&v)[4] = vv[sub];
+        float *row = stage + sl * STRIDE;
+        const float4 E = *reinterpret_cast<const float4 *>(row + EOFF);
+        float4 acc = fma4(E.x, v[0], zero4());
+        acc = fma4(E.y, v[1], acc);
+        acc = fma4(E.z, v[2], acc);
+        acc = fma4(E.w, v[3], acc);
+        *reinterpret_cast<float4 *>(row + 4 * q) = acc;   // over the (already flushed) gOut quad
+    }
+    __syncthreads();
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, sm.live);
 }
 
 // ------------------------------------------------------------------------------------------------
