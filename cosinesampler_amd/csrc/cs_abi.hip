@@ -284,7 +284,7 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     if (stage == CS_STAGE_FORWARD) return need;
     if (!have_plan) need += plan_layout(N, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : (stage == CS_STAGE_BACKWARD ? C + 8 : C + 4)) * 4);   // fat rows
+    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : C + 4) * 4);   // fat rows
     return need;
 }
 
@@ -330,7 +330,7 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
 dim3 point_grid(const Problem &pb) { return dim3((unsigned)((pb.d.P + kBlock - 1) / kBlock), (unsigned)pb.d.N); }
 
 // three-phase point kernels: per wave 64 fat rows + the node/result record (+ the coefficient record of point_bb)
-size_t q_lds(int stride, bool co) { return (size_t)4 * (64 * stride + tl::QREC + (co ? 12 * 64 : 0)) * 4; }
+size_t q_lds(int stride, int co_fields) { return (size_t)4 * (64 * stride + tl::QREC + co_fields * 64) * 4; }
 // point_forward, per wave: one geometry record block + the [C][64] result tile
 size_t point_lds(int C) { return (size_t)4 * (tl::REC_FLOATS + C * tl::OUT_LD) * 4; }
 
@@ -354,24 +354,20 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, false), pb.stream>>>(
-                                          gOut, pr.icl, grid, offset, grad_grid, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 4), pb.stream>>>(
+                                          gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
-    // with grad_input: streams -> fat rows (no gathers), then the tile walkers produce grad_input AND grad_grid
-    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 8) * 4);
+    // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
+    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    size_t shm = (size_t)256 * (pb.d.C + 8) * 4;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward_rows<KERNEL, CQ><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                      gOut, grid, offset, fat, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 4), pb.stream>>>(
+                                      gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
-    tl::zero_dropped_grid_grads<<<point_grid(pb), kBlock, 0, pb.stream>>>(grid, offset, grad_grid, pr.plan, pb.d, pb.f);
-    unsigned nb = (unsigned)((int64_t)pb.d.N * pr.plan.ntiles);
-    CS_DISPATCH_CQ(pb.d.C, (tl::tile_backward<CQ><<<nb, 256, 0, pb.stream>>>(fat, pr.icl, pr.plan, grad_input, grad_grid, pb.d)));
-    return launch_status();
+    return launch_tile_scatter<false>(pb, pr.plan, fat, grad_input);
 }
 
 int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
@@ -397,7 +393,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
-    const size_t shm = q_lds(pb.d.C + 4, true);
+    const size_t shm = q_lds(pb.d.C + 4, 12);
     if (!gInput) {
         if (cIcl) {
             CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
@@ -432,13 +428,13 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (hO) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * pb.d.C + 8, false), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * pb.d.C + 8, 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, false), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;

@@ -453,30 +453,6 @@ __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n
     }
 }
 
-// First backward when grad_input is wanted: NO gathers here.  The point kernel only turns the p-ordered
-// streams into fat rows [gOut(C) | wx0 wx1 wy0 wy1 | d1x d1y 0 0]; the tile kernel, which visits the
-// samples cell by cell and therefore has the 4 node rows of the current cell in registers for free,
-// computes grad_grid as well (tile_backward below).  Trades 4 node-row requests per sample for one
-// scattered 8-byte store.
-template <int KERNEL, int CQ>
-__global__ __launch_bounds__(256) void point_backward_rows(const float *__restrict__ gOut, const float *__restrict__ grid,
-                                                           const float *__restrict__ offset, float *__restrict__ fat,
-                                                           Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 8;
-    extern __shared__ float lds[];
-    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE);
-    float *row = stage + (threadIdx.x & 63) * STRIDE;
-    Sample2 sm;
-    sm.load<KERNEL, 1>(grid, offset, d, f);
-    float4 g[CQ];
-    load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
-    put_payload<CQ>(row, g);
-    *reinterpret_cast<float4 *>(row + C) = make_float4(sm.ax[0].w[0], sm.ax[0].w[1], sm.ax[1].w[0], sm.ax[1].w[1]);
-    *reinterpret_cast<float4 *>(row + C + 4) = make_float4(sm.ax[0].d1, sm.ax[1].d1, 0.f, 0.f);
-    __syncthreads();
-    flush_rows<STRIDE>(stage, fat, sm.n, d);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Three-phase point kernels.  (Their first version kept lane = sample throughout: 16 float4 gathers per lane
 // cost 64 VGPRs, 136 in total, 3 waves per SIMD, and the gathers alone took 0.67 ms against 0.29 ms with CQ
@@ -525,15 +501,18 @@ __device__ __forceinline__ void q_store_rows(const float *stage, int stride, flo
     store_stream<CQ>(dst, P, o);
 }
 
-// first backward without grad_input: grad_grid only.  LDS stage: [64][C+4] = g | wx0 wx1 wy0 wy1
-template <int KERNEL, int CQ>
+// first backward.  LDS stage row = the fat row [g | W0..W3] (flushed when WANT_ROWS: grad_input is wanted);
+// `co` = [4][64]: wx0 wx1 wy0 wy1 for the grad_grid dot products of phase 2.
+template <int KERNEL, int CQ, bool WANT_ROWS>
 __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ gOut, const float *__restrict__ icl,
-                                                        const float *__restrict__ grid, const float *__restrict__ offset,
-                                                        float *__restrict__ grad_grid, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 4;
+                                                      const float *__restrict__ grid, const float *__restrict__ offset,
+                                                      float *__restrict__ fat, float *__restrict__ grad_grid,
+                                                      Dims d, Flags f) {
+    constexpr int C = 4 * CQ, STRIDE = C + 4, CO = 4 * 64;
     extern __shared__ float lds[];
-    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC);
+    float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC + CO);
     float *rec = stage + 64 * STRIDE;
+    float *co = rec + QREC;
     const int lane = threadIdx.x & 63;
     Sample2 sm;
     sm.load<KERNEL, 1>(grid, offset, d, f);
@@ -542,25 +521,29 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
         load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
         float *row = stage + lane * STRIDE;
         put_payload<CQ>(row, g);
-        *reinterpret_cast<float4 *>(row + C) = make_float4(sm.ax[0].w[0], sm.ax[0].w[1], sm.ax[1].w[0], sm.ax[1].w[1]);
+        if (WANT_ROWS) *reinterpret_cast<float4 *>(row + C) = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
+        co[lane] = sm.ax[0].w[0];
+        co[64 + lane] = sm.ax[0].w[1];
+        co[128 + lane] = sm.ax[1].w[0];
+        co[192 + lane] = sm.ax[1].w[1];
         q_put_nodes(rec, sm);
     }
     __syncthreads();
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     const int q = lane % CQ;
-    float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
+    float4 vv[CQ][4];
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    if (WANT_ROWS) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
         const int sl = sub * (64 / CQ) + lane / CQ;
         const float4(&v)[4] = vv[sub];
-        const float *row = stage + sl * STRIDE;
-        const float4 g4 = *reinterpret_cast<const float4 *>(row + 4 * q);
-        const float4 w = *reinterpret_cast<const float4 *>(row + C);   // wx0 wx1 wy0 wy1
+        const float4 g4 = *reinterpret_cast<const float4 *>(stage + sl * STRIDE + 4 * q);
+        const float wx0 = co[sl], wx1 = co[64 + sl], wy0 = co[128 + sl], wy1 = co[192 + sl];
         float d0 = dot4(v[0], g4), d1 = dot4(v[1], g4), d2 = dot4(v[2], g4), d3 = dot4(v[3], g4);
-        float gx = q_reduce<CQ>(w.z * (d1 - d0) + w.w * (d3 - d2));
-        float gy = q_reduce<CQ>(w.x * (d2 - d0) + w.y * (d3 - d1));
+        float gx = q_reduce<CQ>(wy0 * (d1 - d0) + wy1 * (d3 - d2));
+        float gy = q_reduce<CQ>(wx0 * (d2 - d0) + wx1 * (d3 - d1));
         if (q == 0) {
             rec[4 * 64 + sl] = gx;
             rec[5 * 64 + sl] = gy;
@@ -826,165 +809,6 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
         }
         if (v != 0.f) unsafeAtomicAdd(gi + (int64_t)ch * d.vol + (int64_t)gy * W + gx, v);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// tile kernel of the first backward: grad_input as in tile_scatter, plus grad_grid.  A walker keeps the
-// 4 node rows of its current cell in registers (right-hand pair prefetched one cell ahead), so
-//   grad_grid[s] = d1 * sum_c gOut[c] * (signed node differences)       (2d.cu:476-503)
-// costs 4 dot products and two CQ-lane shuffles per sample and one 8-byte store at the sample's id.
-// ------------------------------------------------------------------------------------------------
-template <int CQ>
-__global__ __launch_bounds__(256) void tile_backward(const float *__restrict__ fat, const float *__restrict__ icl,
-                                                     Plan pl, float *__restrict__ grad_input,
-                                                     float *__restrict__ grad_grid, Dims d) {
-    constexpr int C = 4 * CQ;
-    constexpr int STRIDE = C + 8;
-    constexpr int SEGW = CQ, NSEG = TX / SEGW, NODES = NSEG * (SEGW + 1);
-    constexpr int U = 4;
-    static_assert(TY * NSEG * CQ == 256, "one workgroup = all walkers of a tile");
-    __shared__ float4 top[TY * NODES * CQ];
-    __shared__ float4 bot[TY * NODES * CQ];
-    __shared__ uint32_t cb[CELLS + 1];
-
-    const int64_t t = blockIdx.x;
-    const uint32_t b0 = pl.tile_begin[t], b1 = pl.tile_begin[t + 1];
-    if (b0 == b1) return;
-    const int n = (int)(t / pl.ntiles), tl = (int)(t - (int64_t)n * pl.ntiles);
-    const int ty = tl / pl.ntx, tx = tl - ty * pl.ntx;
-    {
-        const uint32_t *cbeg = pl.cell_begin + t * (CELLS + 1);
-        cb[threadIdx.x] = cbeg[threadIdx.x];
-        if (threadIdx.x == 0) cb[CELLS] = cbeg[CELLS];
-    }
-    __syncthreads();
-
-    const int W = d.size[0], H = d.size[1];
-    const int w = threadIdx.x / CQ, q = threadIdx.x % CQ;
-    const int ly = w / NSEG, seg = w % NSEG;
-    {
-        // node rows of this walker: global node row gy0 (low y) and gy0+1, columns gx0 + local cell index (+1)
-        const int gy0 = ty * TY + ly - 1, gx0 = tx * TX + seg * SEGW - 1;
-        const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C) + q;
-        auto node = [&](int gx, int gy) -> float4 {
-            bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
-            float4 v = tab[ok ? (int64_t)(gy * W + gx) * CQ : 0];
-            return ok ? v : zero4();
-        };
-        float4 vt0 = node(gx0, gy0), vb0 = node(gx0, gy0 + 1);           // current cell, left column
-        float4 vt1 = node(gx0 + 1, gy0), vb1 = node(gx0 + 1, gy0 + 1);   // current cell, right column
-        float4 pt = node(gx0 + 2, gy0), pb = node(gx0 + 2, gy0 + 1);     // next cell's right column
-
-        float4 ct = zero4(), cbm = zero4();
-        float4 a0 = zero4(), a1 = zero4(), a2 = zero4(), a3 = zero4();
-        int cur = 0;
-        float4 *trow = top + ((ly * NSEG + seg) * (SEGW + 1)) * CQ + q;
-        float4 *brow = bot + ((ly * NSEG + seg) * (SEGW + 1)) * CQ + q;
-        const uint32_t *cbr = cb + ly * TX + seg * SEGW;
-        const uint32_t j1 = cbr[SEGW];
-        uint32_t nb = cbr[1];
-        const uint32_t *sorted = pl.sorted + b0;
-        const uint32_t jbeg = cbr[0];
-        uint32_t ids[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) ids[u] = jbeg < j1 ? sorted[min(jbeg + u, j1 - 1)] : 0u;
-        for (uint32_t j = jbeg; j < j1; j += U) {
-            float4 g[U], wq[U];
-            float2 dq[U];
-            uint32_t sid[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                sid[u] = ids[u];
-                const float *row = fat + (int64_t)ids[u] * STRIDE;
-                g[u] = *reinterpret_cast<const float4 *>(row + 4 * q);
-                wq[u] = *reinterpret_cast<const float4 *>(row + C);
-                dq[u] = *reinterpret_cast<const float2 *>(row + C + 4);
-            }
-            if (j + U < j1) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) ids[u] = sorted[min(j + U + u, j1 - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = j + u < j1;
-                if (live) {
-                    while (j + u >= nb) {       // close cells up to the one holding this position
-                        trow[cur * CQ] = make_float4(ct.x + a0.x, ct.y + a0.y, ct.z + a0.z, ct.w + a0.w);
-                        brow[cur * CQ] = make_float4(cbm.x + a2.x, cbm.y + a2.y, cbm.z + a2.z, cbm.w + a2.w);
-                        ct = a1; cbm = a3;
-                        a0 = a1 = a2 = a3 = zero4();
-                        ++cur;
-                        nb = cbr[cur + 1];
-                        vt0 = vt1; vb0 = vb1; vt1 = pt; vb1 = pb;      // slide the node window one cell to the right
-                        pt = node(gx0 + cur + 2, gy0);
-                        pb = node(gx0 + cur + 2, gy0 + 1);
-                    }
-                }
-                // node weights W_a = wx[a&1] * wy[a>>1], exactly the products of point_backward
-                const float4 k = make_float4(wq[u].x * wq[u].z, wq[u].y * wq[u].z, wq[u].x * wq[u].w, wq[u].y * wq[u].w);
-                float gxp = 0.f, gyp = 0.f;
-                if (live) {
-                    a0 = fma4(k.x, g[u], a0); a1 = fma4(k.y, g[u], a1);
-                    a2 = fma4(k.z, g[u], a2); a3 = fma4(k.w, g[u], a3);
-                    const float d0 = dot4(vt0, g[u]), d1 = dot4(vt1, g[u]), d2 = dot4(vb0, g[u]), d3 = dot4(vb1, g[u]);
-                    gxp = wq[u].z * (d1 - d0) + wq[u].w * (d3 - d2);
-                    gyp = wq[u].x * (d2 - d0) + wq[u].y * (d3 - d1);
-                }
-#pragma unroll
-                for (int m = 1; m < CQ; m <<= 1) {      // the CQ lanes of a walker are adjacent and act together
-                    gxp += __shfl_xor(gxp, m, 64);
-                    gyp += __shfl_xor(gyp, m, 64);
-                }
-                if (live && q == 0)
-                    *reinterpret_cast<float2 *>(grad_grid + (int64_t)sid[u] * 2) = make_float2(dq[u].x * gxp, dq[u].y * gyp);
-            }
-        }
-        while (cur < SEGW) {
-            trow[cur * CQ] = make_float4(ct.x + a0.x, ct.y + a0.y, ct.z + a0.z, ct.w + a0.w);
-            brow[cur * CQ] = make_float4(cbm.x + a2.x, cbm.y + a2.y, cbm.z + a2.z, cbm.w + a2.w);
-            ct = a1; cbm = a3;
-            a0 = a1 = a2 = a3 = zero4();
-            ++cur;
-        }
-        trow[SEGW * CQ] = ct;
-        brow[SEGW * CQ] = cbm;
-    }
-    __syncthreads();
-
-    const float *topf = reinterpret_cast<const float *>(top), *botf = reinterpret_cast<const float *>(bot);
-    float *gi = grad_input + (int64_t)n * C * d.vol;
-    for (int idx = threadIdx.x; idx < C * (TY + 1) * (TX + 1); idx += 256) {
-        int lx = idx % (TX + 1);
-        int rest = idx / (TX + 1);
-        int lyy = rest % (TY + 1);
-        int ch = rest / (TY + 1);
-        int gx = tx * TX + lx - 1, gy = ty * TY + lyy - 1;
-        if (gx < 0 || gx >= W || gy < 0 || gy >= H) continue;
-        int sg = lx / SEGW, sl = lx - sg * SEGW;
-        float v = 0.f;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            int s2 = side ? sg - 1 : sg, l2 = side ? SEGW : sl;
-            if (side && sl != 0) continue;
-            if (s2 < 0 || s2 >= NSEG) continue;
-            if (lyy < TY) v += topf[((lyy * NSEG + s2) * (SEGW + 1) + l2) * C + ch];
-            if (lyy > 0) v += botf[(((lyy - 1) * NSEG + s2) * (SEGW + 1) + l2) * C + ch];
-        }
-        if (v != 0.f) unsafeAtomicAdd(gi + (int64_t)ch * d.vol + (int64_t)gy * W + gx, v);
-    }
-}
-
-// grad_grid of the samples the plan dropped (no node in range): zero
-__global__ __launch_bounds__(256) void zero_dropped_grid_grads(const float *__restrict__ grid,
-                                                               const float *__restrict__ offset,
-                                                               float *__restrict__ grad_grid, Plan pl, Dims d, Flags f) {
-    const int n = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= d.P) return;
-    const int64_t s = (int64_t)n * d.P + p;
-    float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
-    Geo2 q = locate(g.x, g.y, d, f, offset[n], pl.ntx);
-    if (!q.valid) *reinterpret_cast<float2 *>(grad_grid + s * 2) = make_float2(0.f, 0.f);
 }
 
 }  // namespace tiled

@@ -42,7 +42,7 @@ def test_loader_binds_and_reports_errors_without_gpu():
     assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
     # ... one fat row (C payload floats + 4 coefficients) per sample in backward (plus the plan unless one is passed in)
     S = 16 << 20
-    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 96
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 80
     assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == (
         S * 96 + lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20))
     # 3D and other power-of-two channel counts: row-atomic scatter into a channels-last scratch of
