@@ -44,7 +44,7 @@ def test_loader_binds_and_reports_errors_without_gpu():
     S = 16 << 20
     assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 80
     assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == (
-        S * 96 + lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20))
+        S * 80 + lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20))
     # 3D and other power-of-two channel counts: row-atomic scatter into a channels-last scratch of
     # input's size (backward stages only); odd channel counts and tiny sample counts need nothing
     T3 = 8 * 8 * 128 ** 3 * 4
