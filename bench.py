@@ -38,9 +38,9 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 # a stage's HIP-event time is the sum of these plus the 64 MiB clear of its grad_input
 STAGE_KERNELS = {
     "forward": ["cs::tiled::pack_channels_last", "cs::tiled::point_forward<0, 4>"],
-    "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward_rows<0, 4>",
-                 "cs::tiled::zero_dropped_grid_grads", "cs::tiled::tile_backward<4>"],
-    "backward_backward": ["cs::tiled::point_bb<0, 4, false>", "cs::tiled::tile_scatter<4, false>"],
+    "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward<0, 4, true>",
+                 "cs::tiled::tile_scatter<4, false>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false, true>", "cs::tiled::tile_scatter<4, false>"],
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true>", "cs::tiled::tile_scatter<4, true>"],
 }
 

@@ -25,10 +25,9 @@ T = 16 * 16 * 256 * 256 * 4
 plan = sum(kb("cs::tiled::" + k) for k in ("plan_count", "plan_scan_chunks", "plan_scan_tiles", "plan_scatter", "plan_tile_sort"))
 stage = {
     "forward": kb("cs::tiled::pack_channels_last") + kb("cs::tiled::point_forward"),
-    "backward": plan + kb("cs::tiled::point_backward_rows") + kb("cs::tiled::zero_dropped_grid_grads")
-                + kb("cs::tiled::tile_backward") + T,
-    "backward_backward": kb("cs::tiled::point_bb") + kb("cs::tiled::tile_scatter<4, false>") + T,
-    "bbb_fused": kb("cs::tiled::point_bbb") + kb("cs::tiled::tile_scatter<4, true>") + T,
+    "backward": plan + kb("cs::tiled::point_backward<") + kb("cs::tiled::tile_scatter<4, false>") + T,
+    "backward_backward": kb("cs::tiled::point_bb<") + kb("cs::tiled::tile_scatter<4, false>") + T,
+    "bbb_fused": kb("cs::tiled::point_bbb<") + kb("cs::tiled::tile_scatter<4, true>") + T,
 }
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --steps 1 --warmup 1 (tools/profile_round.sh %s); raw, see tools/pmc_to_traffic.py" % tag,
            "bytes_per_launch": stage}, open("profiles/stage_traffic.json", "w"), indent=1)
