@@ -170,10 +170,17 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
     int rc = zero_async(acc, T, pb.stream);
     if (rc) return rc;
     const int logC = log2_exact(pb.d.C);
-    const int64_t lanes = pb.d.S << logC;
+    const bool pair = pb.d.C <= 8;   // node rows under 64 bytes go in x-neighbour pairs (same request rate, half the requests)
+    const int64_t lanes = pb.d.S << (logC + (pair ? 1 : 0));
+    if ((lanes + kBlock - 1) / kBlock > (int64_t)INT32_MAX) return CS_ERR_UNSUPPORTED;
     const unsigned nb = (unsigned)((lanes + kBlock - 1) / kBlock);
-    CS_DISPATCH_KERNEL(pb.kernel, (cs::row_scatter<DIM, KERNEL, MODE><<<nb, kBlock, 0, pb.stream>>>(
-                                      grid, offset, gOut, cG, hG, hO, acc, pb.d, pb.f, logC)));
+    if (pair) {
+        CS_DISPATCH_KERNEL(pb.kernel, (cs::row_scatter<DIM, KERNEL, MODE, true><<<nb, kBlock, 0, pb.stream>>>(
+                                          grid, offset, gOut, cG, hG, hO, acc, pb.d, pb.f, logC)));
+    } else {
+        CS_DISPATCH_KERNEL(pb.kernel, (cs::row_scatter<DIM, KERNEL, MODE, false><<<nb, kBlock, 0, pb.stream>>>(
+                                          grid, offset, gOut, cG, hG, hO, acc, pb.d, pb.f, logC)));
+    }
     rc = launch_status();
     if (rc) return rc;
     dim3 g((unsigned)((pb.d.vol + 63) / 64), (unsigned)pb.d.N);

@@ -366,11 +366,14 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
 // (N,spatial...,C).  C lanes share a sample, so one wave instruction adds 64/C whole C-float node
 // rows: the memory side retires ~20 G atomic REQUESTS/s whether a request is one float or a
 // contiguous row (tools/microbench.hip MB4), i.e. C times fewer requests than lane-per-sample.
+// PAIR: rows shorter than 64 bytes (C <= 8) are added two at a time -- the x-neighbours of a sample are adjacent in
+// the channels-last scratch, 2C lanes cover both, and the request rate is the same up to 64 bytes whatever the
+// alignment (tools/microbench_sum.hip A1-A3: 2^25 32-byte rows 1.66 ms, the same data as 2^24 64-byte rows 0.83 ms).
 //   MODE 0: W_a * gOut                 (backward,           2d.cu:469-472 / 3d.cu:507-522)
 //   MODE 1: D_a * gOut                 (backward_backward,  2d.cu:709     / 3d.cu:858-860)
 //   MODE 2: E_a * gOut + D_a * hO      (third backward,     2d.cu:885 / 3d.cu:1063 + modules_2d.py:109-111)
 // ----------------------------------------------------------------------------------------------
-template <int DIM, int KERNEL, int MODE>
+template <int DIM, int KERNEL, int MODE, bool PAIR>
 __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ grid, const float *__restrict__ offset,
                                                    const float *__restrict__ gOut, const float *__restrict__ cG,
                                                    const float *__restrict__ hG, const float *__restrict__ hO,
@@ -378,8 +381,9 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
     constexpr int NC = 1 << DIM;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(t & ((1 << logC) - 1));
+    const int xbit = PAIR ? (int)((t >> logC) & 1) : 0;   // PAIR: this lane's nodes are the ones on its x side
     Sample<DIM> sm;
-    if (!sm.template load_at<KERNEL, (MODE == 0 ? 0 : (MODE == 1 ? 1 : 2))>(t >> logC, grid, offset, d, f, f.align)) return;
+    if (!sm.template load_at<KERNEL, (MODE == 0 ? 0 : (MODE == 1 ? 1 : 2))>(t >> (logC + (PAIR ? 1 : 0)), grid, offset, d, f, f.align)) return;
     const int64_t so = ((int64_t)sm.n * d.P + sm.p) * DIM;
     float cg[DIM], hg[DIM];
 #pragma unroll
@@ -390,25 +394,33 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
     const float g = gOut[(int64_t)sm.n * d.go_ns + (int64_t)c * d.P + sm.p];
     const float h = (MODE == 2 && hO) ? hO[(int64_t)sm.n * d.ho_ns + (int64_t)c * d.P + sm.p] : 0.0f;
     float *dst = acc_cl + (int64_t)sm.n * d.vol * d.C + c;
-#pragma unroll
-    for (int a = 0; a < NC; ++a) {
-        if (sm.node[a] < 0) continue;
-        float v;
+    // contribution of node a (compile-time a: no dynamically indexed registers)
+    auto value = [&](int a) -> float {
         if (MODE == 0) {
             float w = sm.ax[0].w[a & 1];
 #pragma unroll
             for (int j = 1; j < DIM; ++j) w *= sm.ax[j].w[(a >> j) & 1];
-            v = w * g;
-        } else {
-            float dsum = 0.0f, esum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < DIM; ++j) {
-                dsum = fmaf(sm.first(a, j), cg[j], dsum);
-                if (MODE == 2) esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
-            }
-            v = MODE == 1 ? g * dsum : fmaf(g, esum, h * dsum);
+            return w * g;
         }
-        unsafeAtomicAdd(dst + sm.node[a] * d.C, v);
+        float dsum = 0.0f, esum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            dsum = fmaf(sm.first(a, j), cg[j], dsum);
+            if (MODE == 2) esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+        }
+        return MODE == 1 ? g * dsum : fmaf(g, esum, h * dsum);
+    };
+    if (PAIR) {
+#pragma unroll
+        for (int k = 0; k < NC / 2; ++k) {   // lanes with xbit = 0 take node 2k, the others its x-neighbour 2k+1
+            const auto node = xbit ? sm.node[2 * k + 1] : sm.node[2 * k];
+            const float v = xbit ? value(2 * k + 1) : value(2 * k);
+            if (node >= 0) unsafeAtomicAdd(dst + node * d.C, v);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+            if (sm.node[a] >= 0) unsafeAtomicAdd(dst + sm.node[a] * d.C, value(a));
     }
 }
 

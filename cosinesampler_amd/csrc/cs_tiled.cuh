@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
     constexpr int SEGW = CQ;                   // cells per walker
     constexpr int NSEG = TX / SEGW;            // walkers per cell row
     constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
-    constexpr int U = TWO ? 4 : 8;             // samples in flight per walker
+    constexpr int U = TWO ? 4 : 8;             // samples in flight per walker (2..16 measured alike)
     static_assert(TY * NSEG * CQ == 256, "one workgroup = all walkers of a tile");
     __shared__ float4 top[TY * NODES * CQ];    // sums for the nodes on the low-y side of each cell row
     __shared__ float4 bot[TY * NODES * CQ];    // ... on the high-y side

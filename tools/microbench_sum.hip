@@ -117,6 +117,18 @@ __global__ __launch_bounds__(256) void row_fetch(const float4 *src, uint32_t row
     if (r == -12345.f) out[0] = r;
 }
 
+// row atomics into a 512 MiB accumulator: LANES lanes add one contiguous row of LANES floats; the row starts at a
+// multiple of ALIGN floats (ALIGN = LANES: aligned rows; ALIGN = LANES/2: every other row straddles its natural boundary)
+template <int LANES, int ALIGN>
+__global__ __launch_bounds__(256) void atomic_rows(float *dst, uint32_t slot_mask, int64_t rows) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t r = t / LANES;
+    int c = (int)(t % LANES);
+    if (r >= rows) return;
+    uint32_t slot = hash32((uint32_t)r * 2654435761u + 7u) & slot_mask;
+    unsafeAtomicAdd(dst + (int64_t)slot * ALIGN + c, 1.0f);
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 #define TIME(label, ...)                                                                    \
@@ -155,5 +167,14 @@ int main() {
     TIME("R3 2^24 fetches of 80 B rows, random over 2^16 rows (5 MiB, ~L2)", (row_fetch<5><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 16) - 1, F, dout)));
     TIME("R4 2^24 fetches of 128 B-stride rows, random over 2^20 rows (128 MiB)", (row_fetch<8><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
     TIME("R5 2^24 fetches of 64 B-stride rows (G only + coef from next row), 2^20 rows (64 MiB)", (row_fetch<4><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
+    {   // 3D config 4: 2^25 node-row updates of 32 B (C = 8) into 512 MiB
+        float *acc; CK(hipMalloc(&acc, (size_t)512 << 20)); CK(hipMemset(acc, 0, (size_t)512 << 20));
+        const int64_t R = 1 << 25;
+        TIME("A1 2^25 row atomics,  8 lanes x 4 B = 32 B rows, 32 B aligned", (atomic_rows<8, 8><<<R * 8 / 256, 256>>>(acc, (1u << 24) - 1, R)));
+        TIME("A2 2^24 row atomics, 16 lanes x 4 B = 64 B rows, 64 B aligned (pairs of the above)", (atomic_rows<16, 16><<<(R / 2) * 16 / 256, 256>>>(acc, (1u << 23) - 1, R / 2)));
+        TIME("A3 2^24 row atomics, 16 lanes x 4 B = 64 B rows, 32 B aligned (half of them straddle)", (atomic_rows<16, 8><<<(R / 2) * 16 / 256, 256>>>(acc, (1u << 24) - 2, R / 2)));
+        TIME("A4 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 128 B aligned", (atomic_rows<32, 32><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 22) - 1, R / 4)));
+        TIME("A5 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 32 B aligned", (atomic_rows<32, 8><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 24) - 4, R / 4)));
+    }
     return 0;
 }
