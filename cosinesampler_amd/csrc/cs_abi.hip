@@ -453,7 +453,8 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 // rows path with channels-last point kernels (3D, C in {4,8,16})
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
-    return dim == 3 && (C == 4 || C == 8 || C == 16) && rows_applies(N, C, P, vol) && N * P < ((int64_t)1 << 31);
+    return dim == 3 && (C == 4 || C == 8 || C == 16) && rows_applies(N, C, P, vol) && N * P < ((int64_t)1 << 31) &&
+           N * vol < ((int64_t)1 << 31);   // global node ids of the fused scatter are 32-bit
 }
 
 size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_cl, int have_cI) {
@@ -485,6 +486,25 @@ int rcl_forward(const Problem &pb, const float *input, const float *grid, const 
     return launch_status();
 }
 
+// LDS of the fused scatter: 4 waves x 64 records of [payloads | coefficients | node ids]
+template <int DIM>
+size_t rcl_lds(int C, int mode) {
+    const int NC = 1 << DIM, np = mode == 2 ? 2 : 1;
+    return (size_t)256 * (C * np + NC * np + NC) * 4;
+}
+// accumulator -> caller's layout
+int rcl_finish(const Problem &pb, const float *acc, float *out_grad) {
+    dim3 g((unsigned)((pb.d.vol + 63) / 64), (unsigned)pb.d.N);
+    cs::unpack_channels_last<<<g, 256, (size_t)64 * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
+    return launch_status();
+}
+int rcl_accumulator(const Problem &pb, Carve &ws, float *&acc) {
+    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
+    acc = (float *)ws.take((size_t)T * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    return zero_async(acc, T, pb.stream);
+}
+
 template <int DIM>
 int rcl_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
                  float *grad_input, float *grad_grid, const float *input_cl, void *workspace, size_t workspace_bytes) {
@@ -492,13 +512,19 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                      gOut, icl, grid, offset, grad_grid, pb.d, pb.f))));
+    if (!grad_input) {
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, false><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                          gOut, icl, grid, offset, grad_grid, nullptr, pb.d, pb.f))));
+        return launch_status();
+    }
+    float *acc;
+    rc = rcl_accumulator(pb, ws, acc);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, rcl_lds<DIM>(pb.d.C, 0), pb.stream>>>(
+                                      gOut, icl, grid, offset, grad_grid, acc, pb.d, pb.f))));
     rc = launch_status();
-    if (rc || !grad_input) return rc;
-    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
-    if (!ws.ok()) return CS_ERR_WORKSPACE;
-    return row_scatter_into<DIM, 0>(pb, grid, offset, gOut, nullptr, nullptr, nullptr, grad_input, acc);
+    if (rc) return rc;
+    return rcl_finish(pb, acc, grad_input);
 }
 
 template <int DIM>
@@ -509,22 +535,31 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
+    const float *cIcl = nullptr;
     if (cI) {
         float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
         if (rc) return rc;
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                          buf, cG, icl, grid, gOut, offset, gGrid, ggOut, pb.d, pb.f))));
-    } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, false><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                          nullptr, cG, icl, grid, gOut, offset, gGrid, ggOut, pb.d, pb.f))));
+        cIcl = buf;
     }
+    float *acc = nullptr;
+    if (gInput) {
+        rc = rcl_accumulator(pb, ws, acc);
+        if (rc) return rc;
+    }
+    const size_t shm = gInput ? rcl_lds<DIM>(pb.d.C, 1) : 0;
+#define CS_RCL_BB(HAS_CI, SCATTER)                                                                                   \
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, HAS_CI, SCATTER>  \
+                                      <<<pb.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, gOut, offset, gGrid, ggOut, acc, pb.d, pb.f))))
+    if (cIcl && gInput) { CS_RCL_BB(true, true); }
+    else if (cIcl) { CS_RCL_BB(true, false); }
+    else if (gInput) { CS_RCL_BB(false, true); }
+    else { CS_RCL_BB(false, false); }
+#undef CS_RCL_BB
     rc = launch_status();
     if (rc || !gInput) return rc;
-    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
-    if (!ws.ok()) return CS_ERR_WORKSPACE;
-    return row_scatter_into<DIM, 1>(pb, grid, offset, gOut, cG, nullptr, nullptr, gInput, acc);
+    return rcl_finish(pb, acc, gInput);
 }
 
 template <int DIM>
@@ -535,13 +570,14 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                      icl, grid, cG, hG, offset, ggOut, pb.d, pb.f))));
+    float *acc;
+    rc = rcl_accumulator(pb, ws, acc);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, rcl_lds<DIM>(pb.d.C, 2), pb.stream>>>(
+                                      icl, grid, gOut, cG, hG, hO, offset, ggOut, acc, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
-    float *acc = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
-    if (!ws.ok()) return CS_ERR_WORKSPACE;
-    return row_scatter_into<DIM, 2>(pb, grid, offset, gOut, cG, hG, hO, gInput, acc);
+    return rcl_finish(pb, acc, gInput);
 }
 
 bool any_null(std::initializer_list<const void *> ps) {

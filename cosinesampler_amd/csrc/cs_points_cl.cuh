@@ -1,8 +1,11 @@
 // cs_points_cl.cuh -- point kernels for any dimensionality gathering float4 channel quads from the
-// channels-last copy of `input` (one node = one contiguous C-float row).  They produce the
-// p-ordered outputs of a stage only; the input-shaped gradient comes from row_scatter
-// (cs_kernels_direct.cuh).  Used for 3D with C in {4,8,16}: a trilinear sample touches 8 node rows
-// instead of 8*C separate lines of the NCDHW tensor.  Formulas as in cs_kernels_direct.cuh.
+// channels-last copy of `input` (one node = one contiguous C-float row).  Used for 3D with C in {4,8,16}: a
+// trilinear sample touches 8 node rows instead of 8*C separate lines of the NCDHW tensor.  They produce the
+// p-ordered outputs of a stage and, with SCATTER, the input-shaped gradient too: each lane leaves
+// [cotangent values | node coefficients | node ids] of its sample in LDS and the wave then adds whole node rows
+// (x-neighbour pairs when a row is under 64 bytes) into the channels-last accumulator with C or 2C lanes per
+// sample -- the row atomics of row_scatter (cs_kernels_direct.cuh) without a second kernel that recomputes the
+// geometry and re-reads the cotangents channel by channel.  Formulas as in cs_kernels_direct.cuh.
 #pragma once
 #include "cs_kernels_direct.cuh"
 
@@ -35,6 +38,45 @@ __device__ __forceinline__ void gather_quad(const float4 *tab, const Sample<DIM>
         if (sm.node[a] < 0) v[a] = zero4();
 }
 
+// ---- fused row-atomic scatter -------------------------------------------------------------------
+// MODE 0: W_a * gOut   MODE 1: D_a * gOut   MODE 2: E_a * gOut + D_a * hO     (as row_scatter)
+template <int DIM, int CQ, int MODE>
+struct Rec {
+    static constexpr int NC = 1 << DIM, C = 4 * CQ, NP = MODE == 2 ? 2 : 1;
+    static constexpr int COEF = C * NP, IDS = COEF + NC * NP, WORDS = IDS + NC;   // [payloads | coefficients | node ids]
+};
+template <int DIM, int CQ, int MODE>
+__device__ __forceinline__ void rec_put_nodes(float *rec, const Sample<DIM> &sm, const Dims &d, bool live) {
+    int *ids = reinterpret_cast<int *>(rec + Rec<DIM, CQ, MODE>::IDS);
+#pragma unroll
+    for (int a = 0; a < (1 << DIM); ++a)
+        ids[a] = (live && sm.node[a] >= 0) ? (int)((int64_t)sm.n * d.vol + sm.node[a]) : -1;
+}
+template <int DIM, int CQ, int MODE>
+__device__ __forceinline__ void scatter_phase(const float *stage, float *__restrict__ acc_cl) {
+    using R = Rec<DIM, CQ, MODE>;
+    constexpr int NC = R::NC, C = R::C;
+    constexpr bool PAIR = C <= 8;                 // rows under 64 bytes go as x-neighbour pairs
+    constexpr int L = PAIR ? 2 * C : C;           // lanes per sample
+    const int lane = threadIdx.x & 63, sub = lane % L, c = sub % C, xbit = PAIR ? sub / C : 0;
+#pragma unroll 2
+    for (int pass = 0; pass < L; ++pass) {        // 64 / L samples per pass
+        const float *r = stage + (pass * (64 / L) + lane / L) * R::WORDS;
+        const float g = r[c];
+        const float h = MODE == 2 ? r[C + c] : 0.0f;
+        const int *ids = reinterpret_cast<const int *>(r + R::IDS);
+#pragma unroll
+        for (int k = 0; k < (PAIR ? NC / 2 : NC); ++k) {
+            const int a = PAIR ? 2 * k + xbit : k;
+            const int node = ids[a];
+            if (node < 0) continue;
+            float v = r[R::COEF + a] * g;
+            if (MODE == 2) v = fmaf(r[R::COEF + NC + a], h, v);
+            unsafeAtomicAdd(acc_cl + (int64_t)node * C + c, v);
+        }
+    }
+}
+
 template <int DIM, int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, const float *__restrict__ grid,
                                                const float *__restrict__ offset, float *__restrict__ out, Dims d,
@@ -58,13 +100,21 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     }
 }
 
-template <int DIM, int KERNEL, int CQ>
+template <int DIM, int KERNEL, int CQ, bool SCATTER>
 __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, const float *__restrict__ icl,
                                                 const float *__restrict__ grid, const float *__restrict__ offset,
-                                                float *__restrict__ grad_grid, Dims d, Flags f) {
+                                                float *__restrict__ grad_grid, float *__restrict__ acc_cl, Dims d,
+                                                Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
+    using R = Rec<DIM, CQ, 0>;
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
+    float *rec = stage + (threadIdx.x & 63) * R::WORDS;
     Sample<DIM> sm;
-    if (!sm.template load<KERNEL, 1>(grid, offset, d, f, f.align)) return;
+    const bool live = sm.template load<KERNEL, 1>(grid, offset, d, f, f.align);
+    if (!SCATTER && !live) return;
+    if (SCATTER) rec_put_nodes<DIM, CQ, 0>(rec, sm, d, live);
+    if (live) {
     float oth[DIM][NC];
 #pragma unroll
     for (int j = 0; j < DIM; ++j)
@@ -93,18 +143,38 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
     float *gg = grad_grid + ((int64_t)sm.n * d.P + sm.p) * DIM;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) gg[j] = sm.ax[j].d1 * acc[j];
+    if (SCATTER) {
+        float W[NC];
+        sm.weights(W);
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) *reinterpret_cast<float4 *>(rec + 4 * q) = g[q];
+#pragma unroll
+        for (int a = 0; a < NC; ++a) rec[R::COEF + a] = W[a];
+    }
+    }
+    if (SCATTER) {
+        __syncthreads();
+        scatter_phase<DIM, CQ, 0>(stage, acc_cl);
+    }
 }
 
-template <int DIM, int KERNEL, int CQ, bool HAS_CI>
+template <int DIM, int KERNEL, int CQ, bool HAS_CI, bool SCATTER>
 __global__ __launch_bounds__(256) void backward_backward(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                          const float *__restrict__ icl, const float *__restrict__ grid,
                                                          const float *__restrict__ gOut, const float *__restrict__ offset,
-                                                         float *__restrict__ gGrid, float *__restrict__ ggOut, Dims d,
-                                                         Flags f) {
+                                                         float *__restrict__ gGrid, float *__restrict__ ggOut,
+                                                         float *__restrict__ acc_cl, Dims d, Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
     constexpr bool FULL = (DIM == 3);   // mixed second derivatives + gOutInput -> grad_grid (3d.cu:758-771, :837-839)
+    using R = Rec<DIM, CQ, 1>;
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
+    float *rec = stage + (threadIdx.x & 63) * R::WORDS;
     Sample<DIM> sm;
-    if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
+    const bool live = sm.template load<KERNEL, 2>(grid, offset, d, f, f.align);
+    if (!SCATTER && !live) return;
+    if (SCATTER) rec_put_nodes<DIM, CQ, 1>(rec, sm, d, live);
+    if (live) {
     float cg[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[((int64_t)sm.n * d.P + sm.p) * DIM + j] : 0.0f;
@@ -137,6 +207,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 g = load_quad(go + (int64_t)(4 * q) * d.P, d.P);
+        if (SCATTER) *reinterpret_cast<float4 *>(rec + 4 * q) = g;
         float4 v[NC];
         gather_quad<DIM, CQ>(tab, sm, q, v);
         float4 o = zero4();
@@ -169,25 +240,61 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     float *gg = gGrid + ((int64_t)sm.n * d.P + sm.p) * DIM;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) gg[j] = acc[j];
+    if (SCATTER) {
+#pragma unroll
+        for (int a = 0; a < NC; ++a) rec[R::COEF + a] = Dm[a];
+    }
+    }
+    if (SCATTER) {
+        __syncthreads();
+        scatter_phase<DIM, CQ, 1>(stage, acc_cl);
+    }
 }
 
-template <int DIM, int KERNEL, int CQ>
+template <int DIM, int KERNEL, int CQ, bool SCATTER>
 __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const float *__restrict__ grid,
-                                           const float *__restrict__ cG, const float *__restrict__ hG,
-                                           const float *__restrict__ offset, float *__restrict__ ggOut, Dims d,
-                                           Flags f) {
+                                           const float *__restrict__ gOut, const float *__restrict__ cG,
+                                           const float *__restrict__ hG, const float *__restrict__ hO,
+                                           const float *__restrict__ offset, float *__restrict__ ggOut,
+                                           float *__restrict__ acc_cl, Dims d, Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
+    using R = Rec<DIM, CQ, 2>;
+    extern __shared__ float lds[];
+    float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
+    float *rec = stage + (threadIdx.x & 63) * R::WORDS;
     Sample<DIM> sm;
-    if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
-    float Em[NC];
+    const bool live = sm.template load<KERNEL, 2>(grid, offset, d, f, f.align);
+    if (!SCATTER && !live) return;
+    if (SCATTER) rec_put_nodes<DIM, CQ, 2>(rec, sm, d, live);
+    if (live) {
+    float Em[NC], Dm[NC];
 #pragma unroll
-    for (int a = 0; a < NC; ++a) Em[a] = 0.0f;
+    for (int a = 0; a < NC; ++a) Em[a] = Dm[a] = 0.0f;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         int64_t o = ((int64_t)sm.n * d.P + sm.p) * DIM + j;
-        float e = (cG ? cG[o] : 0.0f) * (hG ? hG[o] : 0.0f);
+        float cgj = cG ? cG[o] : 0.0f;
+        float e = cgj * (hG ? hG[o] : 0.0f);
 #pragma unroll
-        for (int a = 0; a < NC; ++a) Em[a] = fmaf(sm.pure2(a, j), e, Em[a]);   // pure terms only (3d.cu:1008-1010)
+        for (int a = 0; a < NC; ++a) {
+            Em[a] = fmaf(sm.pure2(a, j), e, Em[a]);   // pure terms only (3d.cu:1008-1010)
+            if (SCATTER) Dm[a] = fmaf(sm.first(a, j), cgj, Dm[a]);
+        }
+    }
+    if (SCATTER) {   // cotangent streams and coefficients of the scatter: E_a * gOut + D_a * hO
+        const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            *reinterpret_cast<float4 *>(rec + 4 * q) = load_quad(go + (int64_t)(4 * q) * d.P, d.P);
+            float4 h = zero4();
+            if (hO) h = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P);
+            *reinterpret_cast<float4 *>(rec + C + 4 * q) = h;
+        }
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            rec[R::COEF + a] = Em[a];
+            rec[R::COEF + NC + a] = Dm[a];
+        }
     }
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     float *ggo = ggOut + (int64_t)sm.n * C * d.P + sm.p;
@@ -200,6 +307,11 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fma4(Em[a], v[q][a], o);
         store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o);
+    }
+    }
+    if (SCATTER) {
+        __syncthreads();
+        scatter_phase<DIM, CQ, 2>(stage, acc_cl);
     }
 }
 
