@@ -183,8 +183,9 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
     }
     rc = launch_status();
     if (rc) return rc;
-    dim3 g((unsigned)((pb.d.vol + 63) / 64), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)64 * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
+    const int nv = cs::unpack_nv(pb.d.C);
+    dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
+    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
     return launch_status();
 }
 
@@ -494,8 +495,9 @@ size_t rcl_lds(int C, int mode) {
 }
 // accumulator -> caller's layout
 int rcl_finish(const Problem &pb, const float *acc, float *out_grad) {
-    dim3 g((unsigned)((pb.d.vol + 63) / 64), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)64 * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
+    const int nv = cs::unpack_nv(pb.d.C);
+    dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
+    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
     return launch_status();
 }
 int rcl_accumulator(const Problem &pb, Carve &ws, float *&acc) {
