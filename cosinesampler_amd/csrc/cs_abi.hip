@@ -207,27 +207,38 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
     if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
     if (N > 65535 || H * W * C >= ((int64_t)1 << 31)) return false;   // gridDim.y = N; 32-bit node offsets
     if (P > ((int64_t)1 << 24)) return false;                          // plan keys pack (p << 8) | cell
-    if (mode == 2) return true;
+    if (mode == 2 || mode == 3) return true;
     return S >= kTiledMinSamples;
 }
 
 struct PlanLayout {
-    int ntx, nty, ntiles, chunks;
+    int ntx, nty, ntiles, chunks, dense;
     size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
 };
 
+// Crowded tables (the reference's own test shapes: 96 tables of 16x16 cells, 10^5 points): the plan bins by cell
+// directly and cell_scatter gives every (n, cell) bucket a wave.  Needs the cell histogram in LDS (48 KiB) and
+// pays off from about two waves' worth of samples per cell: measured at N=16 C=16 P=2^20, stages + plan,
+// 32^2 cells 4.75 vs 7.47 ms, 64^2 4.70 vs 5.24, 96^2 4.98 vs 4.85 (the plan's per-chunk histograms grow with the cells).
+bool dense_applies(int64_t N, int64_t H, int64_t W, int64_t P) {
+    if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: tile walkers only
+    const int64_t cells = (W + 1) * (H + 1);
+    return cells <= 12288 && P >= 128 * cells && N * cells < (int64_t)INT32_MAX;
+}
+
 PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     PlanLayout L;
-    L.ntx = (int)((W + 1 + tl::TX - 1) / tl::TX);
-    L.nty = (int)((H + 1 + tl::TY - 1) / tl::TY);
+    L.dense = dense_applies(N, H, W, P) ? 1 : 0;
+    L.ntx = L.dense ? (int)(W + 1) : (int)((W + 1 + tl::TX - 1) / tl::TX);
+    L.nty = L.dense ? (int)(H + 1) : (int)((H + 1 + tl::TY - 1) / tl::TY);
     L.ntiles = L.ntx * L.nty;
     L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
     int64_t S = N * P;
     size_t o = 0;
     L.off_sorted = o;     o += align256((size_t)S * 4);
-    L.off_key = o;        o += align256((size_t)S * 4);
+    L.off_key = o;        o += L.dense ? 0 : align256((size_t)S * 4);
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
-    L.off_cell_begin = o; o += align256((size_t)N * L.ntiles * (tl::CELLS + 1) * 4);
+    L.off_cell_begin = o; o += L.dense ? 0 : align256((size_t)N * L.ntiles * (tl::CELLS + 1) * 4);
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
     L.bytes = o;
@@ -246,6 +257,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.nty = L.nty;
     p.ntiles = L.ntiles;
     p.chunks = L.chunks;
+    p.dense = L.dense;
     return p;
 }
 
@@ -260,7 +272,7 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
     tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
     tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
     tl::plan_scatter<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
-    tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl, pb.d.P);
+    if (!L.dense) tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl, pb.d.P);
     return launch_status();
 }
 
@@ -298,6 +310,11 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
 
 template <bool TWO>
 int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *fat, float *grad_input) {
+    if (pl.dense) {   // one wave per (n, cell) bucket
+        unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
+        CS_DISPATCH_CQ(pb.d.C, (tl::cell_scatter<CQ, TWO><<<nbk, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
+        return launch_status();
+    }
     unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntiles);
     CS_DISPATCH_CQ(pb.d.C, (tl::tile_scatter<CQ, TWO><<<nb, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
     return launch_status();

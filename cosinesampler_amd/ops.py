@@ -172,7 +172,8 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
 
 
 def force_path(mode):
-    """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 tiled path wherever it exists."""
+    """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 fast paths wherever they exist,
+    3 = 2 without the wave-per-cell kernel for crowded tables."""
     _lib.load().cs_debug_force_path(int(mode))
 
 

@@ -91,7 +91,8 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int padding_mode, int align_corners, int multicell, void *stream);
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
- * kernels, 2 = the tiled path wherever it is implemented, whatever the size.  Process-wide. */
+ * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
+ * go through the tile walkers, not the wave-per-cell kernel.  Process-wide. */
 void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */

@@ -345,18 +345,24 @@ def test_step_context_follows_in_place_updates():
     assert rel_err(g2, r2) <= 1e-5 and rel_err(g1, r2) > 1e-2
 
 
-@pytest.mark.parametrize("C", [4, 16])
-def test_tiled_path_crowded_tiles(C):
-    """PIXEL-like shape (reference test/test_2d.py: 16x16 cells, 1e5 points): a tile holds tens of
-    thousands of samples, so several workgroups share it (tile_scatter_split)."""
-    N, P, sp = 3, 40000, (16, 16)
-    t = _case(2, N, C, sp, P, seed=4242 + C, spread=1.0)
+@pytest.mark.parametrize("C", [4, 8, 16])
+@pytest.mark.parametrize("P,pad,mode", [(40000, 0, 2), (40000, 1, 2), (40000, 2, 2), (18000, 0, 2), (40000, 0, 3)])
+def test_tiled_path_crowded_tables(C, P, pad, mode):
+    """PIXEL-like shape (reference test/test_2d.py: 16x16 cells, 1e5 points): hundreds of samples per cell and the
+    whole table inside one tile.  From 128 samples per cell on (P >= 128 * 17 * 17 = 36992) the plan bins by cell and
+    a wave per (n, cell) bucket does the sums (cell_scatter); below that, or in mode 3, the tile walkers do."""
+    N, sp = 3, (16, 16)
+    t = _case(2, N, C, sp, P, seed=4242 + C, spread=1.1)
     off = offsets(N, True)
-    want = _run_all_stages(cs_oracle, t, off, 0, True, 0, True, "cpu")
-    got = _run_all_stages(_Shared(), t, off, 0, True, 0, True, DEV)      # S = 120000: tiled path by itself
-    torch.cuda.synchronize()
+    want = _run_all_stages(cs_oracle, t, off, pad, True, 0, True, "cpu")
+    ops.force_path(mode)   # 3: the walkers on a crowded table, too
+    try:
+        got = _run_all_stages(_Shared(), t, off, pad, True, 0, True, DEV)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
     for k in want:
-        assert_close(got[k], want[k], "crowded C=%d: %s" % (C, k))
+        assert_close(got[k], want[k], "crowded C=%d P=%d pad=%d: %s" % (C, P, pad, k))
 
 
 def test_tiled_path_empty_and_clustered_points():

@@ -19,6 +19,8 @@ gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
 off = multicell_offset(N, True, dev)
 a = (0, True, 0, True)
+if os.environ.get("CS_FORCE"):
+    ops.force_path(int(os.environ["CS_FORCE"]))
 sc = ops.StepContext()
 stages = {
     "forward": lambda: ops.forward(cells, grid, off, *a, ctx=sc),
