@@ -131,6 +131,40 @@ def helmholtz_step(N, C, H, P, dev, steps=3):
     return e0.elapsed_time(e1) / steps
 
 
+def small_table_step(dev, steps=20):
+    """The reference's own test shapes (test/test_2d.py:24-38: 96 tables of 16x16 cells, 4 channels, 1e5 points):
+    the same forward + three backward stages, fresh StepContext per step.  -> ms per step."""
+    from cosinesampler_amd import multicell_offset, ops
+    N, C, H, P = 96, 4, 16, 100000
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cells = torch.rand(N, C, H, H, generator=g).to(dev)
+    xy = (torch.rand(P, 2, generator=g) * 2 - 1).to(dev)
+    grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    gOut = torch.randn(N, C, 1, P, generator=g).to(dev)
+    hO = torch.randn(N, C, 1, P, generator=g).to(dev)
+    cG = torch.randn(N, 1, P, 2, generator=g).to(dev)
+    hG = torch.randn(N, 1, P, 2, generator=g).to(dev)
+    off = multicell_offset(N, True, dev)
+
+    def one():
+        sc = ops.StepContext()
+        ops.forward(cells, grid, off, 0, True, 0, True, ctx=sc)
+        ops.backward(gOut, cells, grid, off, 0, True, True, 0, True, ctx=sc)
+        ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, 0, True, ctx=sc)
+        ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, 0, True, ctx=sc)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        one()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, N * P
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +304,11 @@ def main():
         }
         if world == 1 and not args.no_helmholtz:
             del out_keep[:]
+            ms_small, S_small = small_table_step(dev)
+            line["reference_test_shapes"] = {
+                "ms_per_step": ms_small, "Msamples_per_s": S_small / ms_small / 1e3,
+                "what": "same four stages at the reference test scripts' shapes: N=96 C=4 H=W=16 P=100000 "
+                        "(test/test_2d.py); crowded tables -> plan by cell + wave-per-cell scatter"}
             ms = helmholtz_step(N, C, H, P, dev)
             line["pixel_helmholtz_autograd"] = {
                 "ms_per_step": ms, "Msamples_per_s": S / ms / 1e3,
