@@ -129,6 +129,61 @@ __global__ __launch_bounds__(256) void atomic_rows(float *dst, uint32_t slot_mas
     unsafeAtomicAdd(dst + (int64_t)slot * ALIGN + c, 1.0f);
 }
 
+// gathers only, table by table without the 64-bit division of S1: blockIdx.y = n
+__global__ __launch_bounds__(256) void quad_gather_n(const float4 *table, int64_t nodes_per_n, int W, int64_t P, float *out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t p = t >> 2;
+    int q = (int)(t & 3), n = blockIdx.y;
+    if (p >= P) return;
+    uint32_t h = hash32((uint32_t)p * 2654435761u + 17u);
+    float fx = (h & 0xffff) * (1.0f / 65536.0f) * (W - 2), fy = (h >> 16) * (1.0f / 65536.0f) * (W - 2);
+    float off = n * (1.0f / 16.0f);
+    int x = (int)(fx + off), y = (int)(fy + off);
+    const float4 *base = table + ((int64_t)n * nodes_per_n + (int64_t)y * W + x) * 4 + q;
+    float4 a = base[0], b = base[4], c = base[(int64_t)W * 4], d = base[(int64_t)W * 4 + 4];
+    float r = a.x + b.y + c.z + d.w;
+    if (r == -12345.f) out[0] = r;
+}
+// pure stream: copy n4 float4
+__global__ __launch_bounds__(256) void stream_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src) + i);
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst) + i);
+    }
+}
+
+// one launch, two roles: even workgroups gather (as quad_gather_n), odd workgroups copy (as stream_copy)
+__global__ __launch_bounds__(256) void mixed_roles(const float4 *table, int64_t nodes_per_n, int W, int64_t P, float *out,
+                                                   const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4,
+                                                   int64_t gather_blocks_per_n) {
+    const int64_t b = blockIdx.x >> 1;
+    if (blockIdx.x & 1) {
+        int64_t i = b * 256 + threadIdx.x;
+        if (i < n4) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src) + i);
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst) + i);
+        }
+    } else {
+        int n = (int)(b / gather_blocks_per_n);
+        if (n >= 16) return;
+        int64_t t = (b - (int64_t)n * gather_blocks_per_n) * 256 + threadIdx.x;
+        int64_t p = t >> 2;
+        int q = (int)(t & 3);
+        if (p >= P) return;
+        uint32_t h = hash32((uint32_t)p * 2654435761u + 17u);
+        float fx = (h & 0xffff) * (1.0f / 65536.0f) * (W - 2), fy = (h >> 16) * (1.0f / 65536.0f) * (W - 2);
+        float off = n * (1.0f / 16.0f);
+        int x = (int)(fx + off), y = (int)(fy + off);
+        const float4 *base = table + ((int64_t)n * nodes_per_n + (int64_t)y * W + x) * 4 + q;
+        float4 a = base[0], bb = base[4], c = base[(int64_t)W * 4], d = base[(int64_t)W * 4 + 4];
+        float r = a.x + bb.y + c.z + d.w;
+        if (r == -12345.f) out[0] = r;
+    }
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 #define TIME(label, ...)                                                                    \
@@ -167,6 +222,27 @@ int main() {
     TIME("R3 2^24 fetches of 80 B rows, random over 2^16 rows (5 MiB, ~L2)", (row_fetch<5><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 16) - 1, F, dout)));
     TIME("R4 2^24 fetches of 128 B-stride rows, random over 2^20 rows (128 MiB)", (row_fetch<8><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
     TIME("R5 2^24 fetches of 64 B-stride rows (G only + coef from next row), 2^20 rows (64 MiB)", (row_fetch<4><<<F / 16 * 4 / 256, 256>>>(rows, (1u << 20) - 1, F, dout)));
+    {   // do L2-resident gathers and HBM streams overlap when they run side by side (two streams)?
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        hipEvent_t f1, f2; CK(hipEventCreate(&f1)); CK(hipEventCreate(&f2));
+        float4 *src, *dst; const int64_t n4 = (int64_t)1 << 26;   // 1 GiB each way
+        CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMemset(src, 0, n4 * 16));
+        dim3 gg((unsigned)(P * 4 / 256), 16);
+        TIME("O1 gathers alone (2^24 samples, table by table)", (quad_gather_n<<<gg, 256>>>(table, nodes, W, P, dout)));
+        TIME("O2 stream copy alone (1 GiB read + 1 GiB write)", (stream_copy<<<n4 / 256, 256>>>(src, dst, n4)));
+        TIME("O3 both, one after the other on one stream", ({ quad_gather_n<<<gg, 256>>>(table, nodes, W, P, dout); stream_copy<<<n4 / 256, 256>>>(src, dst, n4); }));
+        TIME("O4 both, side by side on two streams", ({
+            CK(hipEventRecord(f1, 0)); CK(hipStreamWaitEvent(s1, f1, 0)); CK(hipStreamWaitEvent(s2, f1, 0));
+            quad_gather_n<<<gg, 256, 0, s1>>>(table, nodes, W, P, dout);
+            stream_copy<<<n4 / 256, 256, 0, s2>>>(src, dst, n4);
+            CK(hipEventRecord(f1, s1)); CK(hipEventRecord(f2, s2));
+            CK(hipStreamWaitEvent(0, f1, 0)); CK(hipStreamWaitEvent(0, f2, 0)); }));
+        {   // gather blocks: 16 * P*4/256 = 262144 ; copy blocks: n4/256 = 262144 -> interleave 1:1
+            const int64_t gpn = P * 4 / 256;
+            TIME("O5 both in ONE launch, workgroups alternate roles", (mixed_roles<<<(unsigned)(2 * 16 * gpn), 256>>>(table, nodes, W, P, dout, src, dst, n4, gpn)));
+        }
+        CK(hipFree(src)); CK(hipFree(dst));
+    }
     {   // 3D config 4: 2^25 node-row updates of 32 B (C = 8) into 512 MiB
         float *acc; CK(hipMalloc(&acc, (size_t)512 << 20)); CK(hipMemset(acc, 0, (size_t)512 << 20));
         const int64_t R = 1 << 25;
