@@ -233,32 +233,14 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
 //                                   fetches 64/CQ whole node rows with 4 float4 registers per lane instead of
 //                                   16, so many more requests are in flight per SIMD.
 // ------------------------------------------------------------------------------------------------
-// Stream accesses (each element touched once per kernel) are marked nontemporal so that they do
-// not displace the feature table from L2 / Infinity Cache.
-#ifndef CS_NT_STREAMS
-#define CS_NT_STREAMS 1
-#endif
-// sc1 store (agent-scope relaxed): written through and DROPPED from the XCD's L2, so a 1 GiB output stream
-// leaves the 4 MiB table slice in place.  Only worth it when a wave instruction writes whole lines
-// (lane = sample kernels: 256 contiguous bytes); with point_forward's 64-byte segments it measured 45 %
-// slower than the nontemporal store, which is why both exist.
+// Stream accesses (each element touched once per kernel) must not displace the feature table from the L2:
+// loads are nontemporal; output stores are sc1 (agent-scope relaxed: written through and dropped from the XCD's
+// L2) -- worth it because every wave instruction writes whole lines (256 contiguous bytes); the fat rows leave
+// with nontemporal stores (flush_rows).
 __device__ __forceinline__ void st_stream_wt(float *p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_stream(float *p, float v) {
-#if CS_NT_STREAMS
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ float ld_stream(const float *p) {
-#if CS_NT_STREAMS
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
@@ -336,12 +318,6 @@ __device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs,
 }
 __device__ __forceinline__ float4 load_quad(const float *src, int64_t P) {
     return make_float4(ld_stream(src), ld_stream(src + P), ld_stream(src + 2 * P), ld_stream(src + 3 * P));
-}
-__device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o) {
-    st_stream(dst, o.x);
-    st_stream(dst + P, o.y);
-    st_stream(dst + 2 * P, o.z);
-    st_stream(dst + 3 * P, o.w);
 }
 template <int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
