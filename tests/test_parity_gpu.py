@@ -365,6 +365,47 @@ def test_tiled_path_crowded_tables(C, P, pad, mode):
         assert_close(got[k], want[k], "crowded C=%d P=%d pad=%d: %s" % (C, P, pad, k))
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 48, 30000), (96, 4, 16, 40000), (2, 3, 20, 3000)])
+def test_stages_can_be_captured_in_a_hip_graph(shape):
+    """Nothing in a stage allocates through HIP, synchronises or touches the host, so a whole
+    step -- channels-last copy, plan, forward and the three backward stages -- can be captured into a HIP graph and
+    replayed on new data in the same buffers (what a launch-bound PIXEL loop wants).  Tiled, crowded and direct paths."""
+    N, C, S, P = shape
+    g = torch.Generator().manual_seed(77)
+    cells = torch.rand(N, C, S, S, generator=g).to(DEV)
+    grid = (torch.rand(N, 1, P, 2, generator=g) * 2.2 - 1.1).to(DEV)
+    gO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    cG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
+    hG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
+    hO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    off = offsets(N, True).to(DEV)
+
+    def step():
+        sc = ops.StepContext()
+        out = ops.forward(cells, grid, off, 0, True, 0, True, ctx=sc)
+        gI, gG = ops.backward(gO, cells, grid, off, 0, True, True, 0, True, ctx=sc)
+        bI, bG, bO = ops.backward_backward(None, cG, cells, grid, gO, off, 0, True, False, 0, True, ctx=sc)
+        tI, tO = ops.bbb_fused(cells, grid, gO, cG, hG, hO, off, 0, True, 0, True, ctx=sc)
+        return [out, gI, gG, bI, bG, bO, tI, tO]
+
+    step()                                   # warm up: library load, allocator pools
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    for trial in range(2):                   # new data in the captured input buffers
+        cells.copy_(torch.rand(N, C, S, S, generator=g))
+        grid.copy_(torch.rand(N, 1, P, 2, generator=g) * 2.2 - 1.1)
+        gO.copy_(torch.randn(N, C, 1, P, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in captured]
+        want = step()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert_close(a, b, "graph replay %d, output %d" % (trial, i), tol=2e-6)
+
+
 def test_tiled_path_empty_and_clustered_points():
     """Degenerate point sets for the plan: every point in one cell, every point out of range."""
     N, C, sp = 2, 16, (40, 33)
