@@ -58,6 +58,16 @@ def test_loader_binds_and_reports_errors_without_gpu():
     # argument validation happens before any device work: callable without a GPU
     rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, None, None, 0, None)
     assert rc == -1  # padding_mode 7 is not a mode
+    # a cotangent layout with a negative n-stride is refused; NULL pointers for live sizes are, too
+    bad = _lib.CotangentLayout(-1, 16)
+    rc = lib.cs2d_backward(None, None, None, None, None, None, 1, 1, 4, 4, 8, 0, 1, 0, 1, bad, None, None, None, 0, None)
+    assert rc == -1
+    ok = _lib.CotangentLayout(0, 0)          # n-expanded cotangents: fine as a layout, but the pointers are missing
+    rc = lib.cs2d_backward(None, None, None, None, None, None, 1, 1, 4, 4, 8, 0, 1, 0, 1, ok, None, None, None, 0, None)
+    assert rc == -1
+    # zero-sized problems are a no-op, null pointers and all (empty tensors come with null data pointers)
+    rc = lib.cs2d_backward(None, None, None, None, None, None, 0, 1, 4, 4, 8, 0, 1, 0, 1, None, None, None, None, 0, None)
+    assert rc == 0
 
 
 def test_code_object_is_gfx950():
