@@ -534,21 +534,21 @@ def test_edge_shapes(d):
         Fn.apply(inp, grid[:1])
 
 
-def _full_size_inputs():
-    # BASELINE.json configs[1]: 2D cosine, multicell, N=16 C=16 H=W=256 P=2^20
+def _full_size_inputs(N=16, C=16, H=256, P=1 << 20):
+    # default: BASELINE.json configs[1]: 2D cosine, multicell, N=16 C=16 H=W=256 P=2^20
     torch.manual_seed(0)
-    N, C, H, P = 16, 16, 256, 1 << 20
     inp = torch.rand(N, C, H, H, device=DEV)
     xy = torch.rand(P, 2, device=DEV) * 2 - 1
     grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
     return inp, grid
 
 
-def test_full_size_2d_properties():
+@pytest.mark.parametrize("N,C,H,P", [(16, 16, 256, 1 << 20), (96, 4, 16, 100000)])
+def test_full_size_2d_properties(N, C, H, P):
     """At full size the oracle is too slow; check identities that do not depend on size:
-       partition of unity, linearity, and the adjoint identities linking each stage pair."""
-    inp, grid = _full_size_inputs()
-    N, C, H, P = 16, 16, 256, 1 << 20
+       partition of unity, linearity, and the adjoint identities linking each stage pair.
+       BASELINE config 2 (tile walkers) and the reference test scripts' own shapes (crowded tables: wave per cell)."""
+    inp, grid = _full_size_inputs(N, C, H, P)
     off = multicell_offset(N, True, DEV)
     args = (0, True, 0, True)
     # 1. weights sum to one: a constant field samples to the constant (all nodes in range here)
