@@ -131,6 +131,9 @@ __device__ __forceinline__ Axis make_axis(float g, int size, const Flags &f, int
     bool sane = (i > -1073741824.0f) && (i < 1073741824.0f);
     a.lo = sane ? (int)fl : -4;
     float t = (fl + 1.0f) - i;  // "ix_right - ix", 2d.cu:315
+    // ... and gets finite weights, so that such a sample yields zeros on every path instead of NaN * 0
+    // (the reference leaves this to undefined float->int conversions)
+    if (!sane) { t = 0.5f; i = 0.5f; fl = 0.0f; mu = 0.0f; }
     float k0, k1, k2;
     kern_eval<KERNEL, ORDER>(t, k0, k1, k2);
     a.w[0] = k0;

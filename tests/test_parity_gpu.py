@@ -406,6 +406,32 @@ def test_stages_can_be_captured_in_a_hip_graph(shape):
             assert_close(a, b, "graph replay %d, output %d" % (trial, i), tol=2e-6)
 
 
+@pytest.mark.parametrize("d,C,force", [(2, 16, 2), (2, 3, 0), (2, 32, 2), (3, 8, 2), (3, 3, 0)])
+def test_non_finite_coordinates_give_zeros(d, C, force):
+    """NaN / +-Inf / absurdly large grid coordinates touch no node: every output of every stage is finite, and the
+    rows of those samples are exactly zero, on every path (the reference leaves this case to undefined casts)."""
+    N, P = 2, 3000
+    sp = (37, 50) if d == 2 else (6, 9, 7)
+    t = _case(d, N, C, sp, P, seed=1234 + C, spread=1.1)
+    bad = torch.tensor([float("nan"), float("inf"), -float("inf"), 3e38, -1e30])
+    gv = t["grid"].view(N, P, d)
+    for k in range(5):
+        gv[:, 10 + k, k % d] = bad[k]
+    off = offsets(N, True)
+    ops.force_path(force)
+    try:
+        for pad in (0, 1, 2):
+            got = _run_all_stages(_Shared(), t, off, pad, True, 0, True, DEV)
+            torch.cuda.synchronize()
+            for k, v in got.items():
+                assert bool(torch.isfinite(v).all()), "pad %d: %s has non-finite values" % (pad, k)
+            if pad == 0:
+                assert float(got["out"].view(N, C, P)[:, :, 10:15].abs().max()) == 0.0
+                assert float(got["gG"].view(N, P, d)[:, 10:15].abs().max()) == 0.0
+    finally:
+        ops.force_path(0)
+
+
 def test_tiled_path_empty_and_clustered_points():
     """Degenerate point sets for the plan: every point in one cell, every point out of range."""
     N, C, sp = 2, 16, (40, 33)
