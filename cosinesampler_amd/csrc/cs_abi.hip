@@ -32,6 +32,8 @@ struct Problem {
 int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                  int padding_mode, int align_corners, int kernel, int multicell, void *stream) {
     if (N < 0 || C < 0 || P < 0 || D < 1 || H < 1 || W < 1) return CS_ERR_INVALID;
+    const int exact = (kernel & CS_KERNEL_EXACT_MIXED) ? 1 : 0;
+    kernel &= ~CS_KERNEL_EXACT_MIXED;
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
     // node indices and sizes are kept in 32-bit registers; element offsets are 64-bit
     if (N > INT32_MAX || C > INT32_MAX || D > (1 << 28) || H > (1 << 28) || W > (1 << 28)) return CS_ERR_UNSUPPORTED;
@@ -53,6 +55,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
+    pb.f.exact = exact;
     pb.stream = (hipStream_t)stream;
     pb.blocks = (unsigned)((S + kBlock - 1) / kBlock);
     return CS_OK;
@@ -744,10 +747,12 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
-    if (tiled)
+    // exact + grad_out_input: the grad_out_input -> grad_grid term is only in the direct kernel (run_bb)
+    const bool via_rows = rows || (tiled && pb.f.exact && grad_out_input);
+    if (tiled && !via_rows)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
-    if (rows) {
+    if (via_rows) {
         int rc = run_bb<2>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
         if (rc || !grad_input) return rc;

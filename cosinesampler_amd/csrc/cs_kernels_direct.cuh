@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
     const float *__restrict__ grid, const float *__restrict__ gOut, const float *__restrict__ offset,
     float *__restrict__ gInput, float *__restrict__ gGrid, float *__restrict__ ggOut, Dims d, Flags f) {
     constexpr int NC = 1 << DIM;
-    constexpr bool FULL = (DIM == 3);
+    const bool FULL = (DIM == 3) || f.exact;   // 2D: the reference keeps pure terms only unless asked otherwise
     Sample<DIM> sm;
     if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
     float cg[DIM];
@@ -329,6 +329,11 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
         for (int j = 0; j < DIM; ++j) {
             dsum = fmaf(sm.first(a, j), cg[j], dsum);
             esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+            if (f.exact) {   // + the mixed terms H_jk hG_j cG_k the reference drops (2d.cu:833-834, 3d.cu:1008-1010)
+#pragma unroll
+                for (int k = 0; k < DIM; ++k)
+                    if (k != j) esum = fmaf(sm.mixed2(a, j, k), hg[j] * cg[k], esum);
+            }
         }
         Dm[a] = dsum;
         Em[a] = esum;
@@ -406,7 +411,14 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
             dsum = fmaf(sm.first(a, j), cg[j], dsum);
-            if (MODE == 2) esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+            if (MODE == 2) {
+                esum = fmaf(sm.pure2(a, j), hg[j] * cg[j], esum);
+                if (f.exact) {
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k)
+                        if (k != j) esum = fmaf(sm.mixed2(a, j, k), hg[j] * cg[k], esum);
+                }
+            }
         }
         return MODE == 1 ? g * dsum : fmaf(g, esum, h * dsum);
     };

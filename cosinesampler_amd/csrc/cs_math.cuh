@@ -29,6 +29,7 @@ struct Flags {
     int pad;
     int align;      // as given by the caller
     int multicell;
+    int exact;      // CS_KERNEL_EXACT_MIXED: keep the mixed second derivatives the reference drops (include/cosine_sampler.h)
 };
 
 // k, k', k'' at t in [0,1] (2d.cu:239-261).  ORDER = highest derivative wanted.

@@ -274,11 +274,21 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
     for (int j = 0; j < DIM; ++j) {
         int64_t o = ((int64_t)sm.n * d.P + sm.p) * DIM + j;
         float cgj = cG ? cG[o] : 0.0f;
-        float e = cgj * (hG ? hG[o] : 0.0f);
+        float hgj = hG ? hG[o] : 0.0f;
+        float e = cgj * hgj;
 #pragma unroll
         for (int a = 0; a < NC; ++a) {
-            Em[a] = fmaf(sm.pure2(a, j), e, Em[a]);   // pure terms only (3d.cu:1008-1010)
+            Em[a] = fmaf(sm.pure2(a, j), e, Em[a]);   // pure terms only (3d.cu:1008-1010) ...
             if (SCATTER) Dm[a] = fmaf(sm.first(a, j), cgj, Dm[a]);
+        }
+        if (f.exact) {                                // ... unless the mixed ones are asked for
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                if (k == j) continue;
+                float ek = hgj * (cG ? cG[o - j + k] : 0.0f);
+#pragma unroll
+                for (int a = 0; a < NC; ++a) Em[a] = fmaf(sm.mixed2(a, j, k), ek, Em[a]);
+            }
         }
     }
     if (SCATTER) {   // cotangent streams and coefficients of the scatter: E_a * gOut + D_a * hO

@@ -393,6 +393,10 @@ struct Sample2 {
         float sgn = ((a >> j) & 1) ? -ax[j].d2 : ax[j].d2;
         return sgn * ax[1 - j].w[(a >> (1 - j)) & 1];
     }
+    __device__ __forceinline__ float mixed2(int a) const {   // d2 W_a / dx dy
+        float sx = (a & 1) ? ax[0].d1 : -ax[0].d1, sy = (a & 2) ? ax[1].d1 : -ax[1].d1;
+        return sx * sy;
+    }
 };
 
 template <int CQ>
@@ -567,8 +571,14 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
-            co[a * 64 + lane] = sm.pure2(a, 0) * cg.x;         // Sx: 2D keeps pure second derivatives only (2d.cu:705-706)
-            co[(4 + a) * 64 + lane] = sm.pure2(a, 1) * cg.y;   // Sy
+            float sx = sm.pure2(a, 0) * cg.x, sy = sm.pure2(a, 1) * cg.y;   // 2D keeps pure second derivatives only
+            if (f.exact) {                                                    // (2d.cu:705-706) unless asked otherwise
+                const float mx = sm.mixed2(a);
+                sx = fmaf(mx, cg.y, sx);
+                sy = fmaf(mx, cg.x, sy);
+            }
+            co[a * 64 + lane] = sx;
+            co[(4 + a) * 64 + lane] = sy;
             if (HAS_CI) co[(8 + a) * 64 + lane] = sm.W[a];
         }
         *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         for (int a = 0; a < 4; ++a) {
             Dm[a] = sm.first(a, 0) * cg.x + sm.first(a, 1) * cg.y;
             Em[a] = sm.pure2(a, 0) * (hg.x * cg.x) + sm.pure2(a, 1) * (hg.y * cg.y);   // 2d.cu:876
+            if (f.exact) Em[a] = fmaf(sm.mixed2(a), hg.x * cg.y + hg.y * cg.x, Em[a]);
         }
         float *row = stage + lane * STRIDE;
         float4 g[CQ];

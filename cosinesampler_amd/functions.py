@@ -38,13 +38,17 @@ def padding_mode_enum(padding_mode):
 
 
 _KERNELS = {"cosine": 0, "bilinear": 1, "trilinear": 1, "linear": 1, "smooth-step": 2, "smoothstep": 2}
+_KERNELS.update({k + "+mixed": v | ops.EXACT_MIXED for k, v in list(_KERNELS.items())})
 
 
 def kernel_enum(kernel):
     """reference modules_2d.py:12-18 / modules_3d.py:12-18.  'bilinear' (2D name) and 'trilinear'
     (3D name) are accepted by both samplers, plus the aliases 'linear' and 'smoothstep'.
     Unknown names give None, which the op layer rejects with a TypeError (the reference's pybind
-    call does the same)."""
+    call does the same).
+    Not in the reference: a '+mixed' suffix ('cosine+mixed', 'smooth-step+mixed', ...) keeps the mixed second
+    derivatives the reference drops, so that u_xy and d(u_xy)/d(cells) taken through autograd are
+    those of the interpolant; everything else, and every result without the suffix, is unchanged."""
     return _KERNELS.get(kernel)
 
 

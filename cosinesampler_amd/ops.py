@@ -16,6 +16,9 @@ import torch
 from . import _lib
 
 
+EXACT_MIXED = 0x100   # CS_KERNEL_EXACT_MIXED (include/cosine_sampler.h): keep the mixed second derivatives
+
+
 def _check(t, name, allow_none=False):
     if t is None:
         if allow_none:
@@ -145,9 +148,10 @@ class StepContext(object):
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None):
-    if kernel not in (0, 1, 2):
+    if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
-        raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), got %r" % (kernel,))
+        raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
+                        "got %r" % (kernel,))
     lib = _lib.load()
     fn = getattr(lib, "cs%dd_%s" % (dim, stage))
     D = shape[2] if dim == 3 else 1

@@ -52,6 +52,12 @@ extern "C" {
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
 enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
+/* OR-ed into `kernel` (not in the reference): keep the MIXED second derivatives d2W/dg_j dg_k, j != k, that the
+ * reference drops -- in the 2D second backward (grad_grid, 2d.cu:705-706; also its grad_out_input -> grad_grid term,
+ * 2d.cu has none, 3d.cu:837-839 does) and in the third backward of both dimensionalities (2d.cu:833-834,
+ * 3d.cu:1008-1010).  With it u_xy and d(u_xy)/d(input) obtained through autograd are the exact derivatives of the
+ * interpolant; without it (default) results are the reference's. */
+#define CS_KERNEL_EXACT_MIXED 0x100
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
 

@@ -260,6 +260,49 @@ def test_autograd_chain_on_fast_paths_vs_composite(d, C):
         assert_close(got[k], want[k], "autograd %dD C=%d %s" % (d, C, k), tol=2e-5)
 
 
+@pytest.mark.parametrize("d,C,kern,force", [(2, 16, "cosine", 0), (2, 4, "smooth-step", 0), (2, 3, "cosine", 0),
+                                            (2, 16, "bilinear", 0), (2, 8, "cosine", 1), (2, 32, "cosine", 2),
+                                            (3, 8, "smooth-step", 0), (3, 3, "cosine", 0)])
+def test_mixed_second_derivatives_with_the_exact_flag(d, C, kern, force):
+    """kernel + '+mixed' (CS_KERNEL_EXACT_MIXED, not in the reference): u_xy, u_yx and d(u_xy)/d(cells) through
+    autograd are those of the interpolant -- compared with the exact-derivative composite.  Without the suffix the 2D
+    op returns u_xy = 0, as the reference does."""
+    from oracle import composite
+    torch.manual_seed(6)
+    N, S, P = 4, 48, 40000
+    cells = torch.rand((N, C) + (S,) * d, device=DEV, requires_grad=True)
+    # keep clear of the cell boundaries, where k'' of cosine/smooth-step jumps (DESIGN.md section 2)
+    coords = [(torch.rand(P, 1, device=DEV) * 1.9 - 0.95).requires_grad_(True) for _ in range(d)]
+    grid = torch.cat(coords, -1).view((1,) * d + (P, d)).repeat((N,) + (1,) * (d + 1))
+    w = torch.randn((N, C) + (1,) * (d - 1) + (P,), device=DEV)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    name = {"cosine": "cosine", "smooth-step": "smoothstep", "bilinear": "linear"}[kern]
+    if d == 3 and kern == "bilinear":
+        kern = "trilinear"
+    g = lambda y, x: torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True, create_graph=True)[0]
+
+    def quantities(sample):
+        u = (sample(cells, grid) * w).sum(dim=(0, 1)).view(P, 1)
+        u_x, u_y = g(u, coords[0]), g(u, coords[1])
+        u_xy, u_yx, u_xx = g(u_x, coords[1]), g(u_y, coords[0]), g(u_x, coords[0])
+        res = {"u_xy": u_xy, "u_yx": u_yx, "u_xx": u_xx, "u_xy_cell": g(u_xy, cells), "u_xx_cell": g(u_xx, cells),
+               "mixed_loss_cell": g(((u_xy + 0.5 * u_xx) ** 2).mean().view(1, 1), cells)}
+        return {k: v.detach() for k, v in res.items()}
+
+    ops.force_path(force)
+    try:
+        got = quantities(lambda c, g_: Fn.apply(c, g_, "zeros", True, kern + "+mixed", True))
+        plain = g((Fn.apply(cells, grid, "zeros", True, kern, True) * w).sum(dim=(0, 1)).view(P, 1), coords[0])
+        plain_xy = torch.autograd.grad(plain, coords[1], torch.ones_like(plain), allow_unused=True)[0]
+    finally:
+        ops.force_path(0)
+    want = quantities(lambda c, g_: composite.grid_sample_nd(c, g_, name, True, True))
+    for k in want:
+        assert_close(got[k], want[k], "exact-mixed %dD C=%d %s %s" % (d, C, kern, k), tol=3e-5)
+    if d == 2:   # the reference's behaviour without the flag: no mixed term at all
+        assert plain_xy is None or float(plain_xy.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("d", [2, 3])
 def test_reference_test_scripts_at_their_own_shapes(d):
     """The reference's two test scripts at their real sizes (test/test_2d.py:20-40: 96 cells of 4x16x16,
