@@ -6,7 +6,12 @@
 //     51 ms per stage at N=16 C=16 P=2^20 and 3.4 ms even with channels-last rows;
 //   * LDS float atomics run at ~0.2 T lane-ops/s chip-wide: accumulating in LDS is no way out;
 //   * plain 64-byte row stores to random slots run at ~3 TB/s, sequential row reads at ~6 TB/s;
-//   * random 4 x 64 B node gathers from a channels-last table run at ~12.5 TB/s (L2->L1 bound).
+//   * random 4 x 64 B node gathers from a channels-last table run at ~200 G rows/s when one 4 MiB table at a
+//     time is hot in the L2, a third of that with all N tables hot -- and they do NOT overlap HBM streams
+//     (tools/microbench_sum.hip O1-O5): a kernel costs t_gather + bytes / 6.5 TB/s, so gathers are issued with as
+//     little register footprint as possible (C/4 lanes per sample) and streams are kept to the algorithmic bytes
+//     plus the fat rows;
+//   * random reads are charged per 64-byte sector: an 80-byte fat row costs 1.6 sectors on average.
 //
 // Structure of one backward stage (grad_input part):
 //   plan   (once per grid)  sort the samples by (n, 16x16-cell tile, cell): `sorted[j]` = sample id
@@ -25,6 +30,8 @@
 //                           hands the right-hand pair to the next cell (shared nodes) and stores
 //                           finished node sums to LDS without atomics; the tile's (TX+1)x(TY+1)
 //                           nodes are then added to grad_input (NCHW), lanes along x.
+//   crowded tables          (>= 128 samples per cell, PIXEL's 16x16 tables): the plan bins by cell directly and
+//                           cell_scatter gives every (n, cell) bucket a wave (end of this file).
 //
 // Reference maths per stage: see cs_kernels_direct.cuh (same formulas, same quirks).
 #pragma once
