@@ -28,9 +28,9 @@ _STAGES = {
 }
 EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_pack_bytes", "cs_pack_input",
             "cs2d_plan_bytes", "cs2d_plan_build", "cs_debug_force_path"]
-           + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES])
+           + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 
@@ -75,6 +75,10 @@ def load():
             layout = [] if stage == "forward" else [ctypes.POINTER(CotangentLayout)]
             fn.argtypes = ([_c_f] * nptr + [_c_i64] * (3 + dim) + [_c_int] * 4 + layout
                            + [_c_f, _c_f, _c_f, _c_sz, _c_f])
+    for dim in (2, 3):   # opt-in third-order grid gradient: 8 pointers, sizes, flags, layout*, stream
+        fn = getattr(lib, "cs%dd_bbb_grid" % dim)
+        fn.restype = _c_int
+        fn.argtypes = [_c_f] * 8 + [_c_i64] * (3 + dim) + [_c_int] * 4 + [ctypes.POINTER(CotangentLayout), _c_f]
     _lib = lib
     return lib
 

@@ -621,6 +621,19 @@ bool any_null(std::initializer_list<const void *> ps) {
     return false;
 }
 
+// Opt-in third-order grid gradient (include/cosine_sampler.h): one direct kernel for both dimensionalities.
+template <int DIM>
+int bbb_grid_impl(Problem &pb, const float *input, const float *grid, const float *grad_output,
+                         const float *grad_out_grid, const float *grad_out_ggrid, const float *grad_out_ggout,
+                         const float *offset, float *grad_grid3) {
+    if (pb.d.S == 0) return CS_OK;
+    if (pb.d.C == 0) return zero_async(grad_grid3, pb.d.S * DIM, pb.stream);
+    CS_DISPATCH_KERNEL(pb.kernel, (cs::direct_bbb_grid<DIM, KERNEL><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                                      grad_grid3, pb.d, pb.f)));
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -906,6 +919,30 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     }
     return run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                       grad_input, grad_grad_out);
+}
+
+int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
+                  const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_grid3,
+                  int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners,
+                  int kernel, int multicell, const cs_cotangent_layout *layout, void *stream) {
+    Problem pb;
+    int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
+    if (rc) return rc;
+    CS_LAYOUT()
+    CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
+}
+
+int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
+                  const float *grad_out_ggrid, const float *grad_out_ggout, const float *offset, float *grad_grid3,
+                  int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode,
+                  int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout, void *stream) {
+    Problem pb;
+    int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
+    if (rc) return rc;
+    CS_LAYOUT()
+    CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
 
 }  // extern "C"

@@ -366,6 +366,88 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
 }
 
 // ----------------------------------------------------------------------------------------------
+// NOT in the reference (its third backward returns no gradient for grid, modules_2d.py:111): d/dgrid of
+//   Phi = <gGrid, hG> + <ggOut, hO>,   gGrid[s,j] = sum_c G sum_a I_a sum_k H_jk[a] cG_k,   ggOut = sum_a I_a D_a
+// (the second backward's outputs with every mixed term, gOutInput absent):
+//   gGrid3[s,l] = sum_a ( A_l[a] <G, I_a> + B_l[a] <hO, I_a> ),   A_l[a] = sum_jk T_jkl[a] hG_j cG_k,  B_l[a] = sum_k H_kl[a] cG_k
+// with T_jkl = d3 W_a / dg_j dg_k dg_l.  Per axis m and node bit b the factor of derivative order n is
+//   n=0: w[b]   n=1: +-d1 (+ for the high node)   n=2: -+d2   n=3: +-d3,   d3 = mu^3 k3(t), k3 = third derivative of the blending kernel.
+// One lane per sample, nodes gathered from the caller's tensor: an opt-in path (u_xxx, u_xxy), not a hot one.
+// ----------------------------------------------------------------------------------------------
+template <int DIM, int KERNEL>
+__global__ __launch_bounds__(256) void direct_bbb_grid(
+    const float *__restrict__ input, const float *__restrict__ grid, const float *__restrict__ gOut,
+    const float *__restrict__ cG, const float *__restrict__ hG, const float *__restrict__ hO,
+    const float *__restrict__ offset, float *__restrict__ gGrid3, Dims d, Flags f) {
+    constexpr int NC = 1 << DIM;
+    Sample<DIM> sm;
+    if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
+    const int64_t so = ((int64_t)sm.n * d.P + sm.p) * DIM;
+    float cg[DIM], hg[DIM], d3[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        cg[j] = cG ? cG[so + j] : 0.0f;
+        hg[j] = hG ? hG[so + j] : 0.0f;
+        d3[j] = third_coef<KERNEL>(grid[so + j], d.size[j], f, f.align, offset[sm.n]);
+    }
+    auto fac = [&](int m, int n, int b) -> float {
+        if (n == 0) return sm.ax[m].w[b];
+        if (n == 1) return b ? sm.ax[m].d1 : -sm.ax[m].d1;
+        if (n == 2) return b ? -sm.ax[m].d2 : sm.ax[m].d2;
+        return b ? d3[m] : -d3[m];
+    };
+    float A[DIM][NC], B[DIM][NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int l = 0; l < DIM; ++l) {
+            float asum = 0.0f, bsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                float hkl = 1.0f;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) hkl *= fac(m, (m == k) + (m == l), (a >> m) & 1);
+                bsum = fmaf(hkl, cg[k], bsum);
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) {
+                    float tj = 1.0f;
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) tj *= fac(m, (m == j) + (m == k) + (m == l), (a >> m) & 1);
+                    asum = fmaf(tj, hg[j] * cg[k], asum);
+                }
+            }
+            A[l][a] = asum;
+            B[l][a] = bsum;
+        }
+    float dg[NC], dh[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) dg[a] = dh[a] = 0.0f;
+    const float *in = input + (int64_t)sm.n * d.C * d.vol;
+    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+    const float *ho = hO ? hO + (int64_t)sm.n * d.ho_ns + sm.p : nullptr;
+    for (int c = 0; c < d.C; ++c) {
+        float v[NC];
+        gather<DIM>(in, sm.node, v, d.tab_ns);
+        const float g = *go, h = ho ? *ho : 0.0f;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            dg[a] = fmaf(g, v[a], dg[a]);
+            dh[a] = fmaf(h, v[a], dh[a]);
+        }
+        in += d.tab_cs;
+        go += d.P;
+        if (ho) ho += d.P;
+    }
+#pragma unroll
+    for (int l = 0; l < DIM; ++l) {
+        float r = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) r = fmaf(A[l][a], dg[a], fmaf(B[l][a], dh[a], r));
+        gGrid3[so + l] = r;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Row-atomic scatter for shapes outside the tiled path (3D; 2D with C = 1,2,32,64): the
 // input-shaped gradient of any backward stage, accumulated into a channels-last scratch
 // (N,spatial...,C).  C lanes share a sample, so one wave instruction adds 64/C whole C-float node

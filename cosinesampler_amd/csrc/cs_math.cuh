@@ -147,4 +147,19 @@ __device__ __forceinline__ Axis make_axis(float g, int size, const Flags &f, int
     return a;
 }
 
+// mu^3 k3(t), k3 = third derivative of the blending kernel of one axis -- only for the opt-in third-order grid gradient (direct_bbb_grid); the hot kernels never
+// need it, so it is not part of Axis.  Same coordinate arithmetic as make_axis.
+template <int KERNEL>
+__device__ __forceinline__ float third_coef(float g, int size, const Flags &f, int align, float off) {
+#pragma clang fp contract(off)
+    float mu;
+    float i = source_index(g, size, f.pad, align, off, f.multicell, mu);
+    if (!((i > -1073741824.0f) && (i < 1073741824.0f))) return 0.0f;
+    float t = (floorf(i) + 1.0f) - i;
+    float k3 = 0.0f;
+    if (KERNEL == K_COSINE) k3 = (-0.5f * kPi * kPi * kPi) * __builtin_amdgcn_sinf(0.5f * t);
+    else if (KERNEL == K_SMOOTHSTEP) k3 = -12.0f;
+    return mu * mu * mu * k3;
+}
+
 }  // namespace cs

@@ -248,7 +248,13 @@ class _SamplerBackwardBackward(Function):
         if gOutgGrid is None and gOutggOut is None:
             return None, None, None, None, None, None, None, None, None
         cfg = ctx.cfg
-        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), _f32(_c(gOutgGrid)),
-                                      _f32(ops.keep_expanded(gOutggOut)), ctx.offset, cfg.pad, cfg.align_corners, cfg.kernel,
-                                      cfg.multicell, ctx=ctx.step)
-        return _as(gInput, input), None, _as(ggOut, gOut), None, None, None, None, None, None
+        hG, hO = _f32(_c(gOutgGrid)), _f32(ops.keep_expanded(gOutggOut))
+        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
+                                      cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
+        # '+mixed' kernels also return the gradient w.r.t. grid here (u_xxx, u_xxy): the reference has none
+        # (modules_2d.py:111).  Terms through gOutInput are not propagated, as everywhere at this level.
+        gGrid3 = None
+        if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and _engine_wants(ctx, 1):
+            gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
+                                      cfg.align_corners, cfg.kernel, cfg.multicell), grid)
+        return _as(gInput, input), gGrid3, _as(ggOut, gOut), None, None, None, None, None, None

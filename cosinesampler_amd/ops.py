@@ -276,3 +276,32 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
           want_plan=True, go_ns=go_ns, ho_ns=ho_ns)
     return grad_input, grad_grad_out
+
+
+def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
+             align_corners, kernel, multicell):
+    """NOT in the reference (whose third backward returns no gradient for grid, modules_2d.py:111): the gradient w.r.t.
+    `grid` of <grad_grid2, grad_out_ggrid> + <grad_grad_out, grad_out_ggout>, the second backward's outputs taken
+    with every mixed term and grad_out_input absent (include/cosine_sampler.h, cs{2,3}d_bbb_grid).  -> like grid."""
+    dim, shape, P = _problem(input, grid)
+    _offset_ok(offset, shape[0], input.device)
+    if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
+        raise TypeError("kernel enum must be 0, 1 or 2, optionally | EXACT_MIXED, got %r" % (kernel,))
+    go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+    _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
+    if grad_out_ggrid is not None:
+        _same(grad_out_ggrid, grid.shape, "grad_out_ggrid", input.device)
+    ho_ns = None
+    if grad_out_ggout is not None:
+        ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
+    grad_grid3 = torch.empty_like(grid)
+    lib = _lib.load()
+    CP = shape[1] * P
+    layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns)
+    with torch.cuda.device(input.device):
+        rc = getattr(lib, "cs%dd_bbb_grid" % dim)(
+            _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(grad_out_ggout),
+            _ptr(offset), _ptr(grad_grid3), *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel),
+            int(bool(multicell)), layout, torch.cuda.current_stream(input.device).cuda_stream)
+    _lib.check(rc, "cs%dd_bbb_grid" % dim)
+    return grad_grid3

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 4
+#define CS_ABI_VERSION 5
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -186,6 +186,24 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                    int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                    int padding_mode, int align_corners, int kernel, int multicell, const cs_cotangent_layout *layout /* nullable */,
                    const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- not in the reference: third-order gradient w.r.t. grid ----------------------------------
+ * The reference's third backward returns no gradient for `grid` (modules_2d.py:111, modules_3d.py:100), so u_xxx or
+ * u_xxy cannot be had from it.  This is d/dgrid of  <grad_grid2, grad_out_ggrid> + <grad_grad_out, grad_out_ggout>
+ * where (grad_grid2, grad_grad_out) are the second backward's outputs with every mixed term (CS_KERNEL_EXACT_MIXED
+ * semantics, whatever the flag in `kernel`) and grad_out_input absent.  grad_grid3 has grid's shape.  Needs no workspace. */
+int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
+                  const float *grad_out_ggrid /* nullable */, const float *grad_out_ggout /* nullable */,
+                  const float *offset, float *grad_grid3,
+                  int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                  int padding_mode, int align_corners, int kernel, int multicell,
+                  const cs_cotangent_layout *layout /* nullable */, void *stream);
+int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_output, const float *grad_out_grid,
+                  const float *grad_out_ggrid /* nullable */, const float *grad_out_ggout /* nullable */,
+                  const float *offset, float *grad_grid3,
+                  int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
+                  int padding_mode, int align_corners, int kernel, int multicell,
+                  const cs_cotangent_layout *layout /* nullable */, void *stream);
 
 #ifdef __cplusplus
 }

@@ -287,6 +287,16 @@ def test_mixed_second_derivatives_with_the_exact_flag(d, C, kern, force):
         u_xy, u_yx, u_xx = g(u_x, coords[1]), g(u_y, coords[0]), g(u_x, coords[0])
         res = {"u_xy": u_xy, "u_yx": u_yx, "u_xx": u_xx, "u_xy_cell": g(u_xy, cells), "u_xx_cell": g(u_xx, cells),
                "mixed_loss_cell": g(((u_xy + 0.5 * u_xx) ** 2).mean().view(1, 1), cells)}
+        # third order w.r.t. the coordinates (the reference returns None there): only with '+mixed'
+        def g1(y, x):   # a derivative that is identically zero (linear kernel) has no graph: read None as zeros
+            if not y.requires_grad:
+                return torch.zeros_like(x)
+            r = torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True, allow_unused=True)[0]
+            return torch.zeros_like(x) if r is None else r
+        res.update({"u_xxx": g1(u_xx, coords[0]), "u_xxy": g1(u_xx, coords[1]), "u_xyx": g1(u_xy, coords[0]),
+                    "u_xyy": g1(u_xy, coords[1])})
+        if d == 3:
+            res["u_xyz"] = g1(u_xy, coords[2])
         return {k: v.detach() for k, v in res.items()}
 
     ops.force_path(force)
