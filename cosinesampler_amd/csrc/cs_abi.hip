@@ -10,6 +10,7 @@
 #include "cs_kernels_direct.cuh"
 #include "cs_points_cl.cuh"
 #include "cs_tiled.cuh"
+#include "cs_dense3d.cuh"
 
 namespace {
 
@@ -491,12 +492,78 @@ bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
            N * vol < ((int64_t)1 << 31);   // global node ids of the fused scatter are 32-bit
 }
 
+// 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, a couple of samples per cell at least, one
+// (node, channel) value per lane in cell_scatter3 (C <= 8)
+bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
+    if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: row atomics only
+    const int64_t cells = (W + 1) * (H + 1) * (D + 1);
+    return (C == 4 || C == 8) && cells <= 12288 && P >= 2 * cells && N * cells < (int64_t)INT32_MAX &&
+           N * P < (int64_t)0xFFFFFFF0ll && N <= 65535;
+}
+struct Plan3Layout {
+    int ntx, nty, ntiles, chunks;
+    size_t off_sorted, off_tile_begin, off_block_hist, off_totals, bytes;
+};
+Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) {
+    Plan3Layout L;
+    L.ntx = (int)(W + 1);
+    L.nty = (int)(H + 1);
+    L.ntiles = (int)((W + 1) * (H + 1) * (D + 1));
+    L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
+    size_t o = 0;
+    L.off_sorted = o;     o += align256((size_t)N * P * 4);
+    L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
+    L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
+    L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
+    L.bytes = o;
+    return L;
+}
+tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
+    char *b = (char *)blob;
+    tl::Plan p;
+    p.sorted = (uint32_t *)(b + L.off_sorted);
+    p.key = nullptr;
+    p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
+    p.cell_begin = nullptr;
+    p.block_hist = (uint32_t *)(b + L.off_block_hist);
+    p.ntx = L.ntx;
+    p.nty = L.nty;
+    p.ntiles = L.ntiles;
+    p.chunks = L.chunks;
+    p.dense = 1;
+    return p;
+}
+int build_plan3(const Problem &pb, const float *grid, const float *offset, void *blob) {
+    Plan3Layout L = plan3_layout(pb.d.N, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
+    tl::Plan pl = plan3_view(L, blob);
+    uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
+    dim3 g((unsigned)L.chunks, (unsigned)pb.d.N);
+    size_t shm = (size_t)L.ntiles * 4;
+    cs::dense3::plan_count3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    int64_t nt = (int64_t)pb.d.N * L.ntiles;
+    tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
+    tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
+    cs::dense3::plan_scatter3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    return launch_status();
+}
+// floats per p-ordered row of the 3D dense path: cl::Rec without the node ids
+int dense3_row_floats(int64_t C, int stage) { return (int)((C + 8) * (stage == CS_STAGE_BBB_FUSED ? 2 : 1)); }
+
 size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_cl, int have_cI) {
     size_t T = align256((size_t)N * C * vol * 4), need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     return need + T;   // + the channels-last accumulator of row_scatter
+}
+size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int have_cl,
+                        int have_plan, int have_cI) {
+    size_t T = align256((size_t)N * C * D * H * W * 4), need = 0;
+    if (!have_cl) need += T;
+    if (stage == CS_STAGE_FORWARD) return need;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    if (!have_plan) need += align256(plan3_layout(N, D, H, W, P).bytes);
+    return need + align256((size_t)N * P * dense3_row_floats(C, stage) * 4);
 }
 
 // resolve the channels-last table (caller's or packed into the workspace)
@@ -540,22 +607,61 @@ int rcl_accumulator(const Problem &pb, Carve &ws, float *&acc) {
     return zero_async(acc, T, pb.stream);
 }
 
+// 3D dense path: plan (caller's or built into the workspace), p-ordered rows, one wave per (n, cell) bucket
+int dense3_prepare(const Problem &pb, const float *grid, const float *offset, const void *plan, Carve &ws, int stage,
+                   tl::Plan &pl, float *&rows) {
+    Plan3Layout L = plan3_layout(pb.d.N, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
+    if (plan) {
+        pl = plan3_view(L, const_cast<void *>(plan));
+    } else {
+        void *blob = ws.take(L.bytes);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = build_plan3(pb, grid, offset, blob);
+        if (rc) return rc;
+        pl = plan3_view(L, blob);
+    }
+    rows = (float *)ws.take((size_t)pb.d.S * dense3_row_floats(pb.d.C, stage) * 4);
+    return ws.ok() ? CS_OK : CS_ERR_WORKSPACE;
+}
+template <int MODE>
+int dense3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, float *grad_input) {
+    unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
+    if (pb.d.C == 4) cs::dense3::cell_scatter3<1, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
+    else cs::dense3::cell_scatter3<2, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
+    return launch_status();
+}
+
 template <int DIM>
 int rcl_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
-                 float *grad_input, float *grad_grid, const float *input_cl, void *workspace, size_t workspace_bytes) {
+                 float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
+                 size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, false><<<pb.blocks, kBlock, 0, pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 0><<<pb.blocks, kBlock, 0, pb.stream>>>(
                                           gOut, icl, grid, offset, grad_grid, nullptr, pb.d, pb.f))));
         return launch_status();
+    }
+    const size_t shm = rcl_lds<DIM>(pb.d.C, 0);
+    if (DIM == 3 && dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P)) {
+        tl::Plan pl;
+        float *rows;
+        rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD, pl, rows);
+        if (rc) return rc;
+        rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                          gOut, icl, grid, offset, grad_grid, rows, pb.d, pb.f))));
+        rc = launch_status();
+        if (rc) return rc;
+        return dense3_scatter<0>(pb, pl, rows, grad_input);
     }
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, rcl_lds<DIM>(pb.d.C, 0), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 1><<<pb.blocks, kBlock, shm, pb.stream>>>(
                                       gOut, icl, grid, offset, grad_grid, acc, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
@@ -565,7 +671,7 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
 template <int DIM>
 int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
            const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut, const float *input_cl,
-           void *workspace, size_t workspace_bytes) {
+           const void *plan, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
@@ -578,8 +684,16 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
         if (rc) return rc;
         cIcl = buf;
     }
-    float *acc = nullptr;
-    if (gInput) {
+    const bool dense = gInput && DIM == 3 &&
+                       dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
+    float *acc = nullptr;     // channels-last accumulator (row atomics) or the p-ordered rows (dense)
+    tl::Plan pl;
+    if (dense) {
+        rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD_BACKWARD, pl, acc);
+        if (rc) return rc;
+        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+    } else if (gInput) {
         rc = rcl_accumulator(pb, ws, acc);
         if (rc) return rc;
     }
@@ -587,28 +701,45 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
 #define CS_RCL_BB(HAS_CI, SCATTER)                                                                                   \
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, HAS_CI, SCATTER>  \
                                       <<<pb.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, gOut, offset, gGrid, ggOut, acc, pb.d, pb.f))))
-    if (cIcl && gInput) { CS_RCL_BB(true, true); }
-    else if (cIcl) { CS_RCL_BB(true, false); }
-    else if (gInput) { CS_RCL_BB(false, true); }
-    else { CS_RCL_BB(false, false); }
+    if (cIcl && dense) { CS_RCL_BB(true, 2); }
+    else if (cIcl && gInput) { CS_RCL_BB(true, 1); }
+    else if (cIcl) { CS_RCL_BB(true, 0); }
+    else if (dense) { CS_RCL_BB(false, 2); }
+    else if (gInput) { CS_RCL_BB(false, 1); }
+    else { CS_RCL_BB(false, 0); }
 #undef CS_RCL_BB
     rc = launch_status();
     if (rc || !gInput) return rc;
+    if (dense) return dense3_scatter<1>(pb, pl, acc, gInput);
     return rcl_finish(pb, acc, gInput);
 }
 
 template <int DIM>
 int rcl_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
             const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
-            const float *input_cl, void *workspace, size_t workspace_bytes) {
+            const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
+    const size_t shm = rcl_lds<DIM>(pb.d.C, 2);
+    if (DIM == 3 && dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P)) {
+        tl::Plan pl;
+        float *rows;
+        rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BBB_FUSED, pl, rows);
+        if (rc) return rc;
+        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                          icl, grid, gOut, cG, hG, hO, offset, ggOut, rows, pb.d, pb.f))));
+        rc = launch_status();
+        if (rc) return rc;
+        return dense3_scatter<2>(pb, pl, rows, gInput);
+    }
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, true><<<pb.blocks, kBlock, rcl_lds<DIM>(pb.d.C, 2), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 1><<<pb.blocks, kBlock, shm, pb.stream>>>(
                                       icl, grid, gOut, cG, hG, hO, offset, ggOut, acc, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
@@ -657,7 +788,10 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
     if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
-    if (rows_cl_applies(dim, N, C, P, vol)) return rows_cl_workspace(stage, N, C, vol, have_input_cl, have_cI);
+    if (rows_cl_applies(dim, N, C, P, vol)) {
+        if (dense3_applies(N, C, D, H, W, P)) return dense3_workspace(stage, N, C, D, H, W, P, have_input_cl, have_plan, have_cI);
+        return rows_cl_workspace(stage, N, C, vol, have_input_cl, have_cI);
+    }
     if (stage != CS_STAGE_FORWARD && rows_applies(N, C, P, vol)) return align256((size_t)N * C * vol * 4);
     return 0;
 }
@@ -694,6 +828,24 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
     if (!grid || !offset || !plan) return CS_ERR_INVALID;
     if (plan_bytes < plan_layout(N, H, W, P).bytes) return CS_ERR_WORKSPACE;
     return build_plan(pb, grid, offset, plan);
+}
+
+size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
+    if (N <= 0 || C <= 0 || P <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (!rows_cl_applies(3, N, C, P, D * H * W) || !dense3_applies(N, C, D, H, W, P)) return 0;
+    return plan3_layout(N, D, H, W, P).bytes;
+}
+
+int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
+                    int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int multicell,
+                    void *stream) {
+    Problem pb;
+    int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, 0, multicell, stream);
+    if (rc) return rc;
+    if (!rows_cl_applies(3, N, C, P, D * H * W) || !dense3_applies(N, C, D, H, W, P)) return CS_ERR_UNSUPPORTED;
+    if (!grid || !offset || !plan) return CS_ERR_INVALID;
+    if (plan_bytes < plan3_layout(N, D, H, W, P).bytes) return CS_ERR_WORKSPACE;
+    return build_plan3(pb, grid, offset, plan);
 }
 
 #define CS_PROBLEM(dim, D)                                                                                        \
@@ -842,7 +994,7 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
-        return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, workspace,
+        return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                                workspace_bytes);
     if (rows && grad_input) {
         int rc = run_backward<3>(pb, grad_output, table_, grid, offset, nullptr, grad_grid);
@@ -864,7 +1016,7 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
-                         grad_grad_out, input_cl, workspace, workspace_bytes);
+                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bb<3>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
@@ -887,7 +1039,7 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
-                          grad_grad_out, input_cl, workspace, workspace_bytes);
+                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -909,7 +1061,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
     if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
-                          grad_input, grad_grad_out, input_cl, workspace, workspace_bytes);
+                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);

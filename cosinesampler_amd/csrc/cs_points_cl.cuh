@@ -77,6 +77,23 @@ __device__ __forceinline__ void scatter_phase(const float *stage, float *__restr
     }
 }
 
+// SCATTER == 2 (crowded tables, cs_dense3d.cuh): instead of adding them, the wave's records -- payloads and
+// coefficients, without the node ids -- go to HBM as p-ordered rows of Rec::IDS floats for cell_scatter3.
+template <int DIM, int CQ, int MODE>
+__device__ __forceinline__ void flush_records(const float *stage, float *__restrict__ rows, const Dims &d) {
+    using R = Rec<DIM, CQ, MODE>;
+    constexpr int PIECES = R::IDS / 4;   // float4 per row
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+    if (s0 >= d.S) return;
+    const int nlive = (int)(d.S - s0 < 64 ? d.S - s0 : 64);
+    float4 *dst = reinterpret_cast<float4 *>(rows + s0 * R::IDS);
+    for (int item = lane; item < nlive * PIECES; item += 64) {
+        const int row = item / PIECES, piece = item - row * PIECES;
+        dst[item] = *reinterpret_cast<const float4 *>(stage + row * R::WORDS + 4 * piece);
+    }
+}
+
 template <int DIM, int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, const float *__restrict__ grid,
                                                const float *__restrict__ offset, float *__restrict__ out, Dims d,
@@ -100,7 +117,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     }
 }
 
-template <int DIM, int KERNEL, int CQ, bool SCATTER>
+template <int DIM, int KERNEL, int CQ, int SCATTER>
 __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, const float *__restrict__ icl,
                                                 const float *__restrict__ grid, const float *__restrict__ offset,
                                                 float *__restrict__ grad_grid, float *__restrict__ acc_cl, Dims d,
@@ -154,11 +171,12 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
     }
     if (SCATTER) {
         __syncthreads();
-        scatter_phase<DIM, CQ, 0>(stage, acc_cl);
+        if (SCATTER == 1) scatter_phase<DIM, CQ, 0>(stage, acc_cl);
+        else flush_records<DIM, CQ, 0>(stage, acc_cl, d);
     }
 }
 
-template <int DIM, int KERNEL, int CQ, bool HAS_CI, bool SCATTER>
+template <int DIM, int KERNEL, int CQ, bool HAS_CI, int SCATTER>
 __global__ __launch_bounds__(256) void backward_backward(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                          const float *__restrict__ icl, const float *__restrict__ grid,
                                                          const float *__restrict__ gOut, const float *__restrict__ offset,
@@ -247,11 +265,12 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     }
     if (SCATTER) {
         __syncthreads();
-        scatter_phase<DIM, CQ, 1>(stage, acc_cl);
+        if (SCATTER == 1) scatter_phase<DIM, CQ, 1>(stage, acc_cl);
+        else flush_records<DIM, CQ, 1>(stage, acc_cl, d);
     }
 }
 
-template <int DIM, int KERNEL, int CQ, bool SCATTER>
+template <int DIM, int KERNEL, int CQ, int SCATTER>
 __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const float *__restrict__ grid,
                                            const float *__restrict__ gOut, const float *__restrict__ cG,
                                            const float *__restrict__ hG, const float *__restrict__ hO,
@@ -321,7 +340,8 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
     }
     if (SCATTER) {
         __syncthreads();
-        scatter_phase<DIM, CQ, 2>(stage, acc_cl);
+        if (SCATTER == 1) scatter_phase<DIM, CQ, 2>(stage, acc_cl);
+        else flush_records<DIM, CQ, 2>(stage, acc_cl, d);
     }
 }
 

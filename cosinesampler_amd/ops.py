@@ -129,19 +129,17 @@ class StepContext(object):
         return self._cl
 
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
-        if dim != 2:
-            return None
-        key = self._key(grid) + (offset.data_ptr(), shape[2], shape[3], int(padding_mode), bool(align_corners),
-                                 bool(multicell))
+        key = self._key(grid) + (offset.data_ptr(),) + tuple(shape[2:]) + (int(padding_mode), bool(align_corners),
+                                                                            bool(multicell))
         if self._plan_key != key:
-            nbytes = lib.cs2d_plan_bytes(shape[0], shape[1], shape[2], shape[3], P)
+            sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
+            nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
             self._plan, self._plan_key = None, key
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
-                _lib.check(lib.cs2d_plan_build(grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, shape[0],
-                                               shape[1], shape[2], shape[3], P, int(padding_mode),
-                                               int(bool(align_corners)), int(bool(multicell)), stream),
-                           "cs2d_plan_build")
+                _lib.check(getattr(lib, "cs%dd_plan_build" % dim)(
+                    grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, *sizes, int(padding_mode),
+                    int(bool(align_corners)), int(bool(multicell)), stream), "cs%dd_plan_build" % dim)
                 self._plan = buf
         return self._plan
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 5
+#define CS_ABI_VERSION 6
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -94,6 +94,13 @@ int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P);
 int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
+                    int padding_mode, int align_corners, int multicell, void *stream);
+
+/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 12288, C in {4,8},
+ * P >= 2 cells: the reference's test_3d.py shapes): samples binned by cell.  cs3d_plan_bytes returns 0 otherwise. */
+size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
+int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
+                    int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                     int padding_mode, int align_corners, int multicell, void *stream);
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)

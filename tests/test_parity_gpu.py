@@ -139,18 +139,19 @@ class _Shared(object):
 
 
 @pytest.mark.parametrize("d,C,ke,pad,align,mc", ROW_CASES)
-@pytest.mark.parametrize("shared", [False, True])
-def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared):
-    """Shapes outside the tiled path (3D; 2D with C = 2, 32, 64): p-ordered outputs from the direct
-    kernels, input-shaped gradients by row-atomic scatter into a channels-last scratch.  Forced on."""
+@pytest.mark.parametrize("shared,force", [(False, 2), (True, 2), (True, 3)])
+def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared, force):
+    """Shapes outside the tiled path (3D; 2D with C = 2, 32, 64): p-ordered outputs from the direct or channels-last
+    point kernels, input-shaped gradients by row atomics into a channels-last scratch (force 3) or, for the small
+    crowded 3D tables these cases are with C in {4, 8}, by the plan-by-cell + wave-per-cell path (force 2)."""
     N, P = 2, 1500
     sp = (11, 13) if d == 2 else (6, 9, 7)
     t = _case(d, N, C, sp, P, seed=8100 + 10 * C + ke, spread=1.2)
     off = offsets(N, mc)
     want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
-    ops.force_path(2)
+    ops.force_path(force)
     try:
-        # shared: the channels-last copy of `input` is built once and the direct kernels gather from it
+        # shared: the channels-last copy of `input` (and the 3D plan) is built once per step
         got = _run_all_stages(_Shared() if shared else ops, t, off, pad, align, ke, mc, DEV)
         torch.cuda.synchronize()
     finally:
