@@ -131,27 +131,27 @@ def helmholtz_step(N, C, H, P, dev, steps=3):
     return e0.elapsed_time(e1) / steps
 
 
-def small_table_step(dev, steps=20):
-    """The reference's own test shapes (test/test_2d.py:24-38: 96 tables of 16x16 cells, 4 channels, 1e5 points):
-    the same forward + three backward stages, fresh StepContext per step.  -> ms per step."""
+def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10):
+    """forward + the three backward stages on synthetic inputs of the given shape (any of BASELINE.json's configs or
+    the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step)."""
     from cosinesampler_amd import multicell_offset, ops
-    N, C, H, P = 96, 4, 16, 100000
     g = torch.Generator(device="cpu").manual_seed(11)
-    cells = torch.rand(N, C, H, H, generator=g).to(dev)
-    xy = (torch.rand(P, 2, generator=g) * 2 - 1).to(dev)
-    grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
-    gOut = torch.randn(N, C, 1, P, generator=g).to(dev)
-    hO = torch.randn(N, C, 1, P, generator=g).to(dev)
-    cG = torch.randn(N, 1, P, 2, generator=g).to(dev)
-    hG = torch.randn(N, 1, P, 2, generator=g).to(dev)
+    cells = torch.rand((N, C) + (size,) * dim, generator=g).to(dev)
+    pts = (torch.rand(P, dim, generator=g) * 2 - 1).to(dev)
+    grid = pts.view((1,) * dim + (P, dim)).repeat((N,) + (1,) * (dim + 1)).contiguous()
+    oshape = (N, C) + (1,) * (dim - 1) + (P,)
+    gOut = torch.randn(oshape, generator=g).to(dev)
+    hO = torch.randn(oshape, generator=g).to(dev)
+    cG = torch.randn(grid.shape, generator=g).to(dev)
+    hG = torch.randn(grid.shape, generator=g).to(dev)
     off = multicell_offset(N, True, dev)
 
     def one():
         sc = ops.StepContext()
-        ops.forward(cells, grid, off, 0, True, 0, True, ctx=sc)
-        ops.backward(gOut, cells, grid, off, 0, True, True, 0, True, ctx=sc)
-        ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, 0, True, ctx=sc)
-        ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, 0, True, ctx=sc)
+        ops.forward(cells, grid, off, 0, True, kernel, True, ctx=sc)
+        ops.backward(gOut, cells, grid, off, 0, True, True, kernel, True, ctx=sc)
+        ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, kernel, True, ctx=sc)
+        ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, kernel, True, ctx=sc)
 
     for _ in range(3):
         one()
@@ -163,6 +163,15 @@ def small_table_step(dev, steps=20):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps, N * P
+
+
+OTHER_SHAPES = [   # (key, what, dim, N, C, size, P, kernel enum)
+    ("config_3d", "BASELINE.json configs[3]: 3D smooth-step N=8 C=8 128^3 P=2^19", 3, 8, 8, 128, 1 << 19, 2),
+    ("reference_test_shapes", "reference test/test_2d.py shapes: 2D cosine N=96 C=4 16^2 P=100000 (crowded tables)",
+     2, 96, 4, 16, 100000, 0),
+    ("reference_test_shapes_3d", "reference test/test_3d.py shapes: 3D cosine N=50 C=4 16^3 P=100000 (crowded tables)",
+     3, 50, 4, 16, 100000, 0),
+]
 
 
 def main():
@@ -304,11 +313,11 @@ def main():
         }
         if world == 1 and not args.no_helmholtz:
             del out_keep[:]
-            ms_small, S_small = small_table_step(dev)
-            line["reference_test_shapes"] = {
-                "ms_per_step": ms_small, "Msamples_per_s": S_small / ms_small / 1e3,
-                "what": "same four stages at the reference test scripts' shapes: N=96 C=4 H=W=16 P=100000 "
-                        "(test/test_2d.py); crowded tables -> plan by cell + wave-per-cell scatter"}
+            del cells, grid, gOut, hO, cG, hG, acc      # make room: the 3D config holds a 512 MiB table
+            torch.cuda.empty_cache()
+            for key, what, dim_, n_, c_, size_, p_, kern_ in OTHER_SHAPES:   # the same four stages at other shapes
+                ms_o, s_o = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_)
+                line[key] = {"ms_per_step": ms_o, "Msamples_per_s": s_o / ms_o / 1e3, "what": what}
             ms = helmholtz_step(N, C, H, P, dev)
             line["pixel_helmholtz_autograd"] = {
                 "ms_per_step": ms, "Msamples_per_s": S / ms / 1e3,
