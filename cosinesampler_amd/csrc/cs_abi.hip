@@ -230,7 +230,7 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks, dense;
-    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, bytes;
+    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, bytes;
 };
 
 // Crowded tables (the reference's own test shapes: 96 tables of 16x16 cells, 10^5 points): the plan bins by cell
@@ -258,8 +258,18 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     L.off_cell_begin = o; o += L.dense ? 0 : align256((size_t)N * L.ntiles * (tl::CELLS + 1) * 4);
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
+    L.off_bsum = o;       o += align256(((size_t)N * L.ntiles / 1024 + 3) * 4);
     L.bytes = o;
     return L;
+}
+
+// exclusive scan of `totals` (nt bucket sizes) into tile_begin[0..nt]
+int scan_buckets(const uint32_t *totals, uint32_t *tile_begin, uint32_t *bsum, int64_t nt, hipStream_t s) {
+    const int64_t nb = nt / 1024 + 1;   // covers index nt itself, where the grand total goes
+    tl::plan_scan_tiles_local<<<(unsigned)nb, 1024, 0, s>>>(totals, tile_begin, bsum, nt);
+    tl::plan_scan_tiles_sums<<<1, 1024, 0, s>>>(bsum, nb);
+    tl::plan_scan_tiles_add<<<(unsigned)nb, 1024, 0, s>>>(tile_begin, bsum, nt, nb);
+    return launch_status();
 }
 
 tl::Plan plan_view(const PlanLayout &L, void *blob) {
@@ -287,7 +297,7 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
     tl::plan_count<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     int64_t nt = (int64_t)pb.d.N * L.ntiles;
     tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
-    tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
+    scan_buckets(totals, pl.tile_begin, (uint32_t *)((char *)blob + L.off_bsum), nt, pb.stream);
     tl::plan_scatter<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     if (!L.dense) tl::plan_tile_sort<<<(unsigned)nt, 256, 0, pb.stream>>>(pl, pb.d.P);
     return launch_status();
@@ -502,7 +512,7 @@ bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64
 }
 struct Plan3Layout {
     int ntx, nty, ntiles, chunks;
-    size_t off_sorted, off_tile_begin, off_block_hist, off_totals, bytes;
+    size_t off_sorted, off_tile_begin, off_block_hist, off_totals, off_bsum, bytes;
 };
 Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) {
     Plan3Layout L;
@@ -515,6 +525,7 @@ Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) 
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
+    L.off_bsum = o;       o += align256(((size_t)N * L.ntiles / 1024 + 3) * 4);
     L.bytes = o;
     return L;
 }
@@ -542,7 +553,7 @@ int build_plan3(const Problem &pb, const float *grid, const float *offset, void 
     cs::dense3::plan_count3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     int64_t nt = (int64_t)pb.d.N * L.ntiles;
     tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
-    tl::plan_scan_tiles<<<1, 1024, 0, pb.stream>>>(totals, pl.tile_begin, nt);
+    scan_buckets(totals, pl.tile_begin, (uint32_t *)((char *)blob + L.off_bsum), nt, pb.stream);
     cs::dense3::plan_scatter3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     return launch_status();
 }

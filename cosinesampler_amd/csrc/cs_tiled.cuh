@@ -145,30 +145,52 @@ __global__ __launch_bounds__(256) void plan_scan_chunks(Plan pl, int N, uint32_t
     totals[t] = run;
 }
 
-// single workgroup: exclusive scan of the bucket sizes -> tile_begin[0..count]
-__global__ __launch_bounds__(1024) void plan_scan_tiles(const uint32_t *__restrict__ totals,
-                                                        uint32_t *__restrict__ tile_begin, int64_t count) {
+// exclusive scan of the bucket sizes -> tile_begin[0..count], in three small launches: (1) every workgroup scans its
+// 1024 entries in LDS and leaves its total in bsum, (2) one workgroup scans bsum, (3) the workgroup prefixes are added.
+// (A single workgroup sweeping the array took 0.45 ms for the 2.5e5 cell buckets of the reference's 3D test shapes.)
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *part) {   // inclusive, all 1024 threads
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        uint32_t a = threadIdx.x >= (unsigned)s ? part[threadIdx.x - s] : 0;
+        __syncthreads();
+        part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    return part[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void plan_scan_tiles_local(const uint32_t *__restrict__ totals,
+                                                              uint32_t *__restrict__ tile_begin,
+                                                              uint32_t *__restrict__ bsum, int64_t count) {
+    __shared__ uint32_t part[1024];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < count ? totals[i] : 0;
+    const uint32_t inc = block_scan_1024(v, part);
+    if (i < count) tile_begin[i] = inc - v;
+    if (threadIdx.x == 1023) bsum[blockIdx.x] = inc;
+}
+__global__ __launch_bounds__(1024) void plan_scan_tiles_sums(uint32_t *__restrict__ bsum, int64_t nblocks) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < count; base += 1024) {
-        int64_t i = base + threadIdx.x;
-        uint32_t v = i < count ? totals[i] : 0;
-        part[threadIdx.x] = v;
+    for (int64_t base = 0; base < nblocks; base += 1024) {   // one sweep up to 2^20 buckets
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? bsum[i] : 0;
+        const uint32_t inc = block_scan_1024(v, part);
+        if (i < nblocks) bsum[i] = carry + inc - v;
         __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele inclusive scan
-            uint32_t a = threadIdx.x >= (unsigned)s ? part[threadIdx.x - s] : 0;
-            __syncthreads();
-            part[threadIdx.x] += a;
-            __syncthreads();
-        }
-        if (i < count) tile_begin[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
+        if (threadIdx.x == 1023) carry += inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) tile_begin[count] = carry;
+    if (threadIdx.x == 0) bsum[nblocks] = carry;             // grand total
+}
+__global__ __launch_bounds__(1024) void plan_scan_tiles_add(uint32_t *__restrict__ tile_begin,
+                                                            const uint32_t *__restrict__ bsum, int64_t count,
+                                                            int64_t nblocks) {
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < count) tile_begin[i] += bsum[blockIdx.x];
+    if (i == count) tile_begin[count] = bsum[nblocks];
 }
 
 // (chunks, N): give every sample a slot inside its tile bucket (any order), remember who sits there
