@@ -284,6 +284,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.nty = L.nty;
     p.ntiles = L.ntiles;
     p.chunks = L.chunks;
+    p.chunk = tl::CHUNK;
     p.dense = L.dense;
     return p;
 }
@@ -502,16 +503,19 @@ bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
            N * vol < ((int64_t)1 << 31);   // global node ids of the fused scatter are 32-bit
 }
 
-// 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, a couple of samples per cell at least, one
-// (node, channel) value per lane in cell_scatter3 (C <= 8)
+// 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, one (node, channel) value per lane in cell_scatter3
+// (C <= 8), and enough samples per cell for a wave per cell to pay: measured with 32^3-cell tables, 28 samples per cell
+// 1.9 vs 4.9 ms per stage, 2.8 per cell 1.47 vs 1.26 ms -- the threshold is 8
+// the cell histogram of the 3D plan lives in LDS: 160 KiB per workgroup on gfx950 = 40960 bins (a 33^3-cell table fits)
+constexpr int64_t kDense3MaxCells = 40000;
 bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: row atomics only
     const int64_t cells = (W + 1) * (H + 1) * (D + 1);
-    return (C == 4 || C == 8) && cells <= 12288 && P >= 2 * cells && N * cells < (int64_t)INT32_MAX &&
+    return (C == 4 || C == 8) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
            N * P < (int64_t)0xFFFFFFF0ll && N <= 65535;
 }
 struct Plan3Layout {
-    int ntx, nty, ntiles, chunks;
+    int ntx, nty, ntiles, chunks, chunk;
     size_t off_sorted, off_tile_begin, off_block_hist, off_totals, off_bsum, bytes;
 };
 Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) {
@@ -519,7 +523,8 @@ Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) 
     L.ntx = (int)(W + 1);
     L.nty = (int)(H + 1);
     L.ntiles = (int)((W + 1) * (H + 1) * (D + 1));
-    L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
+    L.chunk = L.ntiles > 12288 ? 4 * tl::CHUNK : tl::CHUNK;   // fewer, larger chunks when a histogram is 50-160 KiB
+    L.chunks = (int)((P + L.chunk - 1) / L.chunk);
     size_t o = 0;
     L.off_sorted = o;     o += align256((size_t)N * P * 4);
     L.off_tile_begin = o; o += align256(((size_t)N * L.ntiles + 1) * 4);
@@ -541,6 +546,7 @@ tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
     p.nty = L.nty;
     p.ntiles = L.ntiles;
     p.chunks = L.chunks;
+    p.chunk = L.chunk;
     p.dense = 1;
     return p;
 }
@@ -550,6 +556,13 @@ int build_plan3(const Problem &pb, const float *grid, const float *offset, void 
     uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
     dim3 g((unsigned)L.chunks, (unsigned)pb.d.N);
     size_t shm = (size_t)L.ntiles * 4;
+    if (shm > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in (idempotent, no device work)
+        hipError_t e1 = hipFuncSetAttribute((const void *)cs::dense3::plan_count3,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e2 = hipFuncSetAttribute((const void *)cs::dense3::plan_scatter3,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    }
     cs::dense3::plan_count3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     int64_t nt = (int64_t)pb.d.N * L.ntiles;
     tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);

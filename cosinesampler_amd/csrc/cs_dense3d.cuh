@@ -15,7 +15,6 @@ namespace cs {
 namespace dense3 {
 
 using tiled::Plan;
-using tiled::CHUNK;
 
 struct Cell3 {
     int bin;
@@ -47,8 +46,8 @@ __global__ __launch_bounds__(256) void plan_count3(const float *__restrict__ gri
     for (int b = threadIdx.x; b < pl.ntiles; b += 256) hist[b] = 0;
     __syncthreads();
     const float off = offset[n];
-    const int64_t p0 = (int64_t)chunk * CHUNK;
-    for (int i = threadIdx.x; i < CHUNK; i += 256) {
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
             Cell3 q = locate3(grid + ((int64_t)n * d.P + p) * 3, d, f, off, pl);
@@ -70,8 +69,8 @@ __global__ __launch_bounds__(256) void plan_scatter3(const float *__restrict__ g
     for (int b = threadIdx.x; b < pl.ntiles; b += 256) cursor[b] = tb[b] + excl[b];
     __syncthreads();
     const float off = offset[n];
-    const int64_t p0 = (int64_t)chunk * CHUNK;
-    for (int i = threadIdx.x; i < CHUNK; i += 256) {
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
             int64_t s = (int64_t)n * d.P + p;

@@ -52,6 +52,7 @@ struct Plan {
     uint32_t *cell_begin;  // [N*ntiles*(CELLS+1)] bucket-relative first position of every cell of every tile
     uint32_t *block_hist;  // [N*chunks*ntiles] scratch
     int ntx, nty, ntiles, chunks;
+    int chunk;             // samples per plan workgroup (CHUNK; larger when the histogram is large)
     int dense;             // crowded tables: the bins ARE the cells -- ntx = W+1, ntiles = (W+1)(H+1), `sorted` is written
                            // by plan_scatter directly, no per-tile pass, no cell_begin; consumed by cell_scatter
 };

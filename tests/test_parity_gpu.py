@@ -144,7 +144,7 @@ def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared, f
     """Shapes outside the tiled path (3D; 2D with C = 2, 32, 64): p-ordered outputs from the direct or channels-last
     point kernels, input-shaped gradients by row atomics into a channels-last scratch (force 3) or, for the small
     crowded 3D tables these cases are with C in {4, 8}, by the plan-by-cell + wave-per-cell path (force 2)."""
-    N, P = 2, 1500
+    N, P = 2, 5000   # 3D: 7*10*8 = 560 cells, 8 samples per cell and more -> the dense path applies (force 2)
     sp = (11, 13) if d == 2 else (6, 9, 7)
     t = _case(d, N, C, sp, P, seed=8100 + 10 * C + ke, spread=1.2)
     off = offsets(N, mc)
