@@ -311,7 +311,7 @@ int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipS
     return launch_status();
 }
 
-// carve the workspace: [input_cl?][plan?][cI_cl?][rows1][coef1][rows2][coef2]
+// carve the workspace in the order cs_workspace_bytes adds it up: [input_cl?][plan?][gOutInput channels-last?][fat rows | accumulator]
 struct Carve {
     char *base;
     size_t used, cap;
@@ -496,7 +496,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// rows path with channels-last point kernels (3D, C in {4,8,16})
+// 3D with C in {4,8,16}: channels-last point kernels + fused row atomics, or the dense path for crowded tables
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     return dim == 3 && (C == 4 || C == 8 || C == 16) && rows_applies(N, C, P, vol) && N * P < ((int64_t)1 << 31) &&
@@ -998,7 +998,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
                       grad_input, grad_grad_out);
 }
 
-// ---- 3D (direct path only for now) ----
+// ---- 3D ----
 int cs3d_forward(const float *input, const float *grid, const float *offset, float *output, int64_t N, int64_t C,
                  int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int kernel,
                  int multicell, const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes,
