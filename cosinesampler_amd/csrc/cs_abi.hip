@@ -86,11 +86,14 @@ int zero_async(float *p, int64_t elems, hipStream_t s) {
     return launch_status();
 }
 
-// channel-count dispatch of the tiled path: CQ = C/4 in {1, 2, 4}
+// channel count of a channels-last copy: a whole number of float4 quads (C = 1..3 runs zero-padded to 4 in 2D)
+int64_t cpad(int64_t C) { return (C + 3) & ~(int64_t)3; }
+
+// channel-count dispatch of the fast paths: CQ = cpad(C)/4 in {1, 2, 4}
 #define CS_DISPATCH_CQ(C_, ...)                                               \
-    switch (C_) {                                                             \
-        case 4:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
-        case 8:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
+    switch (((C_) + 3) / 4) {                                                 \
+        case 1:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
+        case 2:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
         default: { constexpr int CQ = 4; __VA_ARGS__; } break;                \
     }
 
@@ -216,7 +219,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     int mode = g_force_path.load(std::memory_order_relaxed);
     if (mode == 1 || dim != 2) return false;
-    if (!(C == 4 || C == 8 || C == 16)) return false;
+    if (!(C <= 4 || C == 8 || C == 16)) return false;   // C = 1..3: zero-padded to one quad
     int64_t S = N * P;
     if (S <= 0 || S >= (int64_t)0xFFFFFFF0ll) return false;
     int64_t ntx = (W + 1 + tl::TX - 1) / tl::TX, nty = (H + 1 + tl::TY - 1) / tl::TY;
@@ -307,7 +310,8 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
 int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipStream_t s) {
     if (N == 0 || C == 0 || vol == 0) return CS_OK;
     dim3 g((unsigned)((vol + 63) / 64), (unsigned)N);
-    tl::pack_channels_last<<<g, 256, (size_t)C * 65 * 4, s>>>(in, out, (int)C, vol);
+    const int64_t CP = cpad(C);
+    tl::pack_channels_last<<<g, 256, (size_t)CP * 65 * 4, s>>>(in, out, (int)C, (int)CP, vol);
     return launch_status();
 }
 
@@ -325,14 +329,15 @@ struct Carve {
 
 size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
                        int have_cI) {
-    size_t T = align256((size_t)N * C * H * W * 4);
+    const int64_t CP = cpad(C);
+    size_t T = align256((size_t)N * CP * H * W * 4);
     size_t S = (size_t)N * P;
     size_t need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (!have_plan) need += plan_layout(N, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * C + 8 : C + 4) * 4);   // fat rows
+    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * CP + 8 : CP + 4) * 4);   // fat rows
     return need;
 }
 
@@ -356,7 +361,7 @@ struct Prepared {
 // resolve input_cl / plan: use the caller's, or build into the workspace
 int prepare(const Problem &pb, int stage, const float *input, const float *grid, const float *offset,
             const float *input_cl, const void *plan, Carve &ws, Prepared &out) {
-    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
+    const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
     if (input_cl) {
         out.icl = input_cl;
     } else {
@@ -393,7 +398,7 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds(pb.d.C), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
     return launch_status();
 }
@@ -407,16 +412,16 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 4), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
                                           gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
     // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
-    float *fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
+    float *fat = (float *)ws.take((size_t)pb.d.S * (cpad(pb.d.C) + 4) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 4), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
                                       gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
@@ -433,7 +438,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
-        float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+        float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
         if (rc) return rc;
@@ -441,12 +446,12 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     }
     float *fat = nullptr;
     if (gInput) {
-        fat = (float *)ws.take((size_t)pb.d.S * (pb.d.C + 4) * 4);
+        fat = (float *)ws.take((size_t)pb.d.S * (cpad(pb.d.C) + 4) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
-    const size_t shm = q_lds(pb.d.C + 4, 12);
+    const size_t shm = q_lds((int)cpad(pb.d.C) + 4, 12);
     if (!gInput) {
         if (cIcl) {
             CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
@@ -476,18 +481,18 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *fat = (float *)ws.take((size_t)pb.d.S * (2 * pb.d.C + 8) * 4);
+    float *fat = (float *)ws.take((size_t)pb.d.S * (2 * cpad(pb.d.C) + 8) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (hO) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * pb.d.C + 8, 0), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * (int)cpad(pb.d.C) + 8, 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(pb.d.C + 4, 0), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
@@ -824,15 +829,15 @@ size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (!tiled_applies(dim, N, C, H, W, P) && !rows_cl_applies(dim, N, C, P, vol)) return 0;
-    return align256((size_t)N * C * vol * 4);
+    return align256((size_t)N * cpad(C) * vol * 4);
 }
 
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
                   int64_t W, void *stream) {
     if (dim != 2 && dim != 3) return CS_ERR_INVALID;
-    if (N < 0 || C < 0 || D < 1 || H < 1 || W < 1 || (C & 3)) return CS_ERR_INVALID;
+    if (N < 0 || C < 0 || D < 1 || H < 1 || W < 1) return CS_ERR_INVALID;
     if (N * C > 0 && (!input || !input_cl)) return CS_ERR_INVALID;
-    if (C * 65 * 4 > 64 * 1024) return CS_ERR_UNSUPPORTED;
+    if (cpad(C) * 65 * 4 > 64 * 1024) return CS_ERR_UNSUPPORTED;
     return pack_cl(input, input_cl, N, C, (dim == 3 ? D : 1) * H * W, (hipStream_t)stream);
 }
 

@@ -81,18 +81,18 @@ __device__ __forceinline__ Geo2 locate(float gx, float gy, const Dims &d, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// channels-last repack:  in (N,C,vol) -> out (N,vol,C), C % 4 == 0
+// channels-last repack:  in (N,C,vol) -> out (N,vol,CP), CP = C rounded up to a multiple of 4 (extra channels zero)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_channels_last(const float *__restrict__ in, float *__restrict__ out,
-                                                          int C, int64_t vol) {
-    extern __shared__ float tile[];  // [C][65]
+                                                          int C, int CP, int64_t vol) {
+    extern __shared__ float tile[];  // [CP][65]
     const int n = blockIdx.y;
     const int64_t v0 = (int64_t)blockIdx.x * 64;
-    const int CQ = C >> 2;
-    for (int idx = threadIdx.x; idx < C * 64; idx += 256) {
+    const int CQ = CP >> 2;
+    for (int idx = threadIdx.x; idx < CP * 64; idx += 256) {
         int c = idx >> 6, v = idx & 63;
         float x = 0.0f;
-        if (v0 + v < vol) x = in[((int64_t)n * C + c) * vol + v0 + v];
+        if (c < C && v0 + v < vol) x = in[((int64_t)n * C + c) * vol + v0 + v];
         tile[c * 65 + v] = x;
     }
     __syncthreads();
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void pack_channels_last(const float *__restric
         if (v0 + v < vol) {
             float4 r = make_float4(tile[(4 * q) * 65 + v], tile[(4 * q + 1) * 65 + v], tile[(4 * q + 2) * 65 + v],
                                    tile[(4 * q + 3) * 65 + v]);
-            *reinterpret_cast<float4 *>(out + (((int64_t)n * vol + v0 + v) * C + 4 * q)) = r;
+            *reinterpret_cast<float4 *>(out + (((int64_t)n * vol + v0 + v) * CP + 4 * q)) = r;
         }
     }
 }
@@ -346,8 +346,14 @@ __device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs,
     for (int a = 0; a < 4; ++a)
         if (qs.node[a] == NO_NODE) v[a] = zero4();
 }
-__device__ __forceinline__ float4 load_quad(const float *src, int64_t P) {
-    return make_float4(ld_stream(src), ld_stream(src + P), ld_stream(src + 2 * P), ld_stream(src + 3 * P));
+// the 4 channels 4q..4q+3 of a channel-major stream; channels >= cv do not exist (C < 4 runs zero-padded as CQ = 1)
+__device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
+    float4 r;
+    r.x = ld_stream(src);
+    r.y = cv > 1 ? ld_stream(src + P) : 0.0f;
+    r.z = cv > 2 ? ld_stream(src + 2 * P) : 0.0f;
+    r.w = cv > 3 ? ld_stream(src + 3 * P) : 0.0f;
+    return r;
 }
 template <int KERNEL, int CQ>
 __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     __syncthreads();
     const int n = blockIdx.y;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
-    float *obase = out + (int64_t)n * C * d.P;
+    float *obase = out + (int64_t)n * d.C * d.P;   // d.C: the caller's channel count (template C is the padded one)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     if (p < d.P) {
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int c = 0; c < C; ++c) st_stream_wt(obase + (int64_t)c * d.P + p, ot[c * OUT_LD + lane]);
+        for (int c = 0; c < C; ++c)
+            if (c < d.C) st_stream_wt(obase + (int64_t)c * d.P + p, ot[c * OUT_LD + lane]);
     }
 }
 
@@ -430,19 +437,20 @@ struct Sample2 {
 };
 
 template <int CQ>
-__device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 (&g)[CQ]) {
+__device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 (&g)[CQ], int C) {
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) g[q] = load_quad(src + (int64_t)(4 * q) * P, P);
+    for (int q = 0; q < CQ; ++q) g[q] = load_quad(src + (int64_t)(4 * q) * P, P, C - 4 * q);
 }
 template <int CQ>
-__device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4 (&o)[CQ]) {
+__device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4 (&o)[CQ], int C) {
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float *p = dst + (int64_t)(4 * q) * P;
+        const int cv = C - 4 * q;
         st_stream_wt(p, o[q].x);
-        st_stream_wt(p + P, o[q].y);
-        st_stream_wt(p + 2 * P, o[q].z);
-        st_stream_wt(p + 3 * P, o[q].w);
+        if (cv > 1) st_stream_wt(p + P, o[q].y);
+        if (cv > 2) st_stream_wt(p + 2 * P, o[q].z);
+        if (cv > 3) st_stream_wt(p + 3 * P, o[q].w);
     }
 }
 // fat row of sample s: payload(s) then coefficient record(s), contiguous, 16-byte aligned.
@@ -512,13 +520,13 @@ __device__ __forceinline__ float q_reduce(float x) {
     return x;
 }
 template <int CQ>
-__device__ __forceinline__ void q_store_rows(const float *stage, int stride, float *dst, int64_t P, bool live) {
+__device__ __forceinline__ void q_store_rows(const float *stage, int stride, float *dst, int64_t P, bool live, int C) {
     if (!live) return;
     const float *row = stage + (threadIdx.x & 63) * stride;
     float4 o[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) o[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
-    store_stream<CQ>(dst, P, o);
+    store_stream<CQ>(dst, P, o, C);
 }
 
 // first backward.  LDS stage row = the fat row [g | W0..W3] (flushed when WANT_ROWS: grad_input is wanted);
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
     sm.load<KERNEL, 1>(grid, offset, d, f);
     {
         float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
         float *row = stage + lane * STRIDE;
         put_payload<CQ>(row, g);
         if (WANT_ROWS) *reinterpret_cast<float4 *>(row + C) = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     {
         float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
         float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
         float *row = stage + lane * STRIDE;
         put_payload<CQ>(row, g);
         float Dm[4];
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
         }
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, sm.live);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P + sm.p, d.P, sm.live, d.C);
     if (sm.live) *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(rec[4 * 64 + lane], rec[5 * 64 + lane]);
 }
 
@@ -681,11 +689,11 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         }
         float *row = stage + lane * STRIDE;
         float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g);
+        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
         put_payload<CQ>(row, g);
         if (TWO) {
             float4 h[CQ];
-            load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h);
+            load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h, d.C);
             put_payload<CQ>(row + C, h);
             *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
         }
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         *reinterpret_cast<float4 *>(row + 4 * q) = acc;   // over the (already flushed) gOut quad
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * C * d.P + sm.p, d.P, sm.live);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P + sm.p, d.P, sm.live, d.C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -819,8 +827,8 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
     // lx % SEGW of run lx / SEGW and, when lx is a run boundary, also the last slot of the run before.
     const int W = d.size[0], H = d.size[1];
     const float *topf = reinterpret_cast<const float *>(top), *botf = reinterpret_cast<const float *>(bot);
-    float *gi = grad_input + (int64_t)n * C * d.vol;
-    for (int idx = threadIdx.x; idx < C * (TY + 1) * (TX + 1); idx += 256) {
+    float *gi = grad_input + (int64_t)n * d.C * d.vol;
+    for (int idx = threadIdx.x; idx < d.C * (TY + 1) * (TX + 1); idx += 256) {   // ch < d.C: padded channels are dropped
         int lx = idx % (TX + 1);
         int rest = idx / (TX + 1);
         int lyy = rest % (TY + 1);
@@ -908,8 +916,8 @@ __global__ __launch_bounds__(256) void cell_scatter(const float *__restrict__ fa
     const int n = (int)(bucket / pl.ntiles), cell = (int)(bucket - (int64_t)n * pl.ntiles);
     const int uy = cell / pl.ntx, ux = cell - uy * pl.ntx;
     const int x = ux - 1 + (a & 1), y = uy - 1 + (a >> 1);
-    if (x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || r == 0.f) return;
-    unsafeAtomicAdd(grad_input + ((int64_t)n * C + c) * d.vol + (int64_t)y * d.size[0] + x, r);
+    if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || r == 0.f) return;
+    unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + (int64_t)y * d.size[0] + x, r);
 }
 
 }  // namespace tiled

@@ -81,8 +81,9 @@ const char *cs_error_string(int code);
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI);
 
-/* Channels-last copy (N,spatial...,C) of an (N,C,spatial...) tensor; C % 4 == 0.  Returns the
- * byte size of the copy / makes it.  cs_pack_bytes returns 0 when the fast path does not apply. */
+/* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C rounded up to a multiple of 4 (the extra
+ * channels are zero: 2D tables with 1..3 channels run as one float4 quad).  Returns the byte size of the copy / makes
+ * it.  cs_pack_bytes returns 0 when no fast path applies. */
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
                   int64_t W, void *stream);
