@@ -97,6 +97,22 @@ int64_t cpad(int64_t C) { return (C + 3) & ~(int64_t)3; }
         default: { constexpr int CQ = 4; __VA_ARGS__; } break;                \
     }
 
+// the 2D tiled path also takes 32 channels (8 quads); the 3D channels-last kernels stop at 16
+#define CS_DISPATCH_CQT(C_, ...)                                              \
+    switch (((C_) + 3) / 4) {                                                 \
+        case 1:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
+        case 2:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
+        case 4:  { constexpr int CQ = 4; __VA_ARGS__; } break;                \
+        default: { constexpr int CQ = 8; __VA_ARGS__; } break;                \
+    }
+// dynamic LDS beyond the default 64 KiB limit needs an opt-in per kernel (idempotent, no device work)
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return CS_OK;
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? CS_OK : (int)e;
+}
+
 // kernel-enum dispatch: KERNEL is a template parameter so the unused derivative paths fold away
 #define CS_DISPATCH_KERNEL(kernel_enum, ...)                                  \
     switch (kernel_enum) {                                                    \
@@ -219,7 +235,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     int mode = g_force_path.load(std::memory_order_relaxed);
     if (mode == 1 || dim != 2) return false;
-    if (!(C <= 4 || C == 8 || C == 16)) return false;   // C = 1..3: zero-padded to one quad
+    if (!(C <= 4 || C == 8 || C == 16 || C == 32)) return false;   // C = 1..3: zero-padded to one quad
     int64_t S = N * P;
     if (S <= 0 || S >= (int64_t)0xFFFFFFF0ll) return false;
     int64_t ntx = (W + 1 + tl::TX - 1) / tl::TX, nty = (H + 1 + tl::TY - 1) / tl::TY;
@@ -345,12 +361,17 @@ template <bool TWO>
 int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *fat, float *grad_input) {
     if (pl.dense) {   // one wave per (n, cell) bucket
         unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
-        CS_DISPATCH_CQ(pb.d.C, (tl::cell_scatter<CQ, TWO><<<nbk, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
+        CS_DISPATCH_CQT(pb.d.C, (tl::cell_scatter<CQ, TWO><<<nbk, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
         return launch_status();
     }
     unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntiles);
-    CS_DISPATCH_CQ(pb.d.C, (tl::tile_scatter<CQ, TWO><<<nb, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
-    return launch_status();
+    int rc = CS_OK;
+    CS_DISPATCH_CQT(pb.d.C, {
+        constexpr size_t shm = tl::tile_scatter_lds<CQ>();
+        rc = allow_lds(tl::tile_scatter<CQ, TWO>, shm);
+        if (!rc) tl::tile_scatter<CQ, TWO><<<nb, 256, shm, pb.stream>>>(fat, pl, grad_input, pb.d);
+    });
+    return rc ? rc : launch_status();
 }
 
 struct Prepared {
@@ -398,7 +419,7 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
     return launch_status();
 }
@@ -412,7 +433,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
                                           gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
@@ -421,7 +442,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
                                       gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
@@ -454,19 +475,19 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     const size_t shm = q_lds((int)cpad(pb.d.C) + 4, 12);
     if (!gInput) {
         if (cIcl) {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                               cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
         } else {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                               cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
         }
         return launch_status();
     }
     if (cIcl) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                           cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bb<KERNEL, CQ, false, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, false, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
                                           cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
     }
     rc = launch_status();
@@ -486,13 +507,18 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (hO) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(2 * (int)cpad(pb.d.C) + 8, 0), pb.stream>>>(
-                                          pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
+        const size_t shm = q_lds(2 * (int)cpad(pb.d.C) + 8, 0);   // 80 KiB at 32 channels
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
+            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true>, shm);
+            if (!rc) tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                         pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f);
+        }));
+        if (rc) return rc;
         rc = launch_status();
         if (rc) return rc;
         return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 0), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;

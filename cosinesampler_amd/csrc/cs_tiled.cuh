@@ -512,11 +512,12 @@ __device__ __forceinline__ void q_gather(const float4 *tab, const float *rec, in
     for (int a = 0; a < 4; ++a)
         if (node[a] == NO_NODE) v[a] = zero4();
 }
-// sum over the CQ lanes of a sample (CQ in {1,2,4}: lanes of one sample are adjacent)
+// sum over the CQ lanes of a sample (CQ in {1,2,4,8}: lanes of one sample are adjacent)
 template <int CQ>
 __device__ __forceinline__ float q_reduce(float x) {
     if (CQ >= 2) x += __shfl_xor(x, 1);
     if (CQ >= 4) x += __shfl_xor(x, 2);
+    if (CQ >= 8) x += __shfl_xor(x, 4);
     return x;
 }
 template <int CQ>
@@ -731,6 +732,10 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
 // fat-row loads stay plain: the CQ lanes of a walker and the payload / coefficient loads of a lane share lines
 // (nontemporal loads here: tile kernels 15 % slower)
 __device__ __forceinline__ float4 ld_row(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <int CQ>
+constexpr size_t tile_scatter_lds() {   // top + bot images + the cell table
+    return (size_t)2 * TY * (TX / CQ) * (CQ + 1) * CQ * 16 + (CELLS + 1 + 3) / 4 * 16;
+}
 template <int CQ, bool TWO>
 __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fat, Plan pl,
                                                     float *__restrict__ grad_input, Dims d) {
@@ -741,9 +746,10 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
     constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
     constexpr int U = TWO ? 4 : 8;             // samples in flight per walker (2..16 measured alike)
     static_assert(TY * NSEG * CQ == 256, "one workgroup = all walkers of a tile");
-    __shared__ float4 top[TY * NODES * CQ];    // sums for the nodes on the low-y side of each cell row
-    __shared__ float4 bot[TY * NODES * CQ];    // ... on the high-y side
-    __shared__ uint32_t cb[CELLS + 1];         // bucket-relative first position of every cell
+    extern __shared__ float4 tile_lds[];       // dynamic: 74 KiB at CQ = 8 (tile_scatter_lds)
+    float4 *top = tile_lds;                    // sums for the nodes on the low-y side of each cell row
+    float4 *bot = top + TY * NODES * CQ;       // ... on the high-y side
+    uint32_t *cb = reinterpret_cast<uint32_t *>(bot + TY * NODES * CQ);   // bucket-relative first position of every cell
 
     const int64_t t = blockIdx.x;
     const uint32_t b0 = pl.tile_begin[t], b1 = pl.tile_begin[t + 1];
@@ -894,30 +900,39 @@ __global__ __launch_bounds__(256) void cell_scatter(const float *__restrict__ fa
                 }
         }
     }
-    // halving exchange: after the step with partner distance m a lane keeps the half of its values selected by
-    // its bit m; after log2(NV) steps lane l holds value (l >> (6 - log2 NV)), summed over the lanes it met
-    int m = 32;
+    // halving exchange: at the step with partner distance m a lane keeps the half of its values selected by its
+    // bit m and receives the partner's copy of that half; six steps (m = 32 .. 1) leave NV / 64 fully reduced values
+    // per lane (NV = 128: values 2 l and 2 l + 1 on lane l); with NV < 64 the last steps are plain butterflies and
+    // 64 / NV lanes share value l / (64 / NV)
+    constexpr int VALS = NV >= 64 ? NV / 64 : 1, SHARE = NV >= 64 ? 1 : 64 / NV;
+    int cur = NV;
 #pragma unroll
-    for (int half = NV / 2; half >= 1; half >>= 1) {
-        const bool up = (lane & m) != 0;
+    for (int m = 32; m >= 1; m >>= 1) {
+        if (cur > VALS) {
+            const int half = cur / 2;
+            const bool up = (lane & m) != 0;
 #pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float lo = v[i], hi = v[i + half];
-            const float got = __shfl_xor(up ? lo : hi, m);
-            v[i] = (up ? hi : lo) + got;
+            for (int i = 0; i < half; ++i) {
+                const float lo = v[i], hi = v[i + half];
+                const float got = __shfl_xor(up ? lo : hi, m);
+                v[i] = (up ? hi : lo) + got;
+            }
+            cur = half;
+        } else {
+            v[0] += __shfl_xor(v[0], m);
         }
-        m >>= 1;
     }
-    float r = v[0];
-    for (; m >= 1; m >>= 1) r += __shfl_xor(r, m);   // NV < 64: finish over the lanes that share a value
-    constexpr int SHARE = 64 / NV;                    // lanes holding the same value
     if (lane % SHARE) return;
-    const int idx = lane / SHARE, a = idx / C, c = idx % C;
     const int n = (int)(bucket / pl.ntiles), cell = (int)(bucket - (int64_t)n * pl.ntiles);
     const int uy = cell / pl.ntx, ux = cell - uy * pl.ntx;
-    const int x = ux - 1 + (a & 1), y = uy - 1 + (a >> 1);
-    if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || r == 0.f) return;
-    unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + (int64_t)y * d.size[0] + x, r);
+#pragma unroll
+    for (int jv = 0; jv < VALS; ++jv) {
+        const int idx = (lane / SHARE) * VALS + jv, a = idx / C, c = idx % C;
+        const int x = ux - 1 + (a & 1), y = uy - 1 + (a >> 1);
+        const float r = v[jv];
+        if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || r == 0.f) continue;
+        unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + (int64_t)y * d.size[0] + x, r);
+    }
 }
 
 }  // namespace tiled

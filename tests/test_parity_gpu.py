@@ -92,6 +92,8 @@ for _C in (4, 8, 16):
         for _pad, _align, _mc in ((0, True, True), (0, False, False), (1, True, False), (2, True, True),
                                   (2, False, False)):
             TILED_CASES.append((_C, _ke, _pad, _align, _mc))
+# 32 channels = 8 quads per sample (LDS of the walkers and of the fused third backward beyond 64 KiB)
+TILED_CASES += [(32, 0, 0, True, True), (32, 2, 1, False, False), (32, 1, 2, True, True)]
 # channel counts below 4 run zero-padded to one quad on the same path
 TILED_CASES += [(1, 0, 0, True, True), (2, 0, 0, True, True), (2, 2, 1, False, False), (3, 1, 2, True, True),
                 (3, 0, 0, False, True)]
@@ -402,7 +404,7 @@ def test_step_context_follows_in_place_updates():
     assert rel_err(g2, r2) <= 1e-5 and rel_err(g1, r2) > 1e-2
 
 
-@pytest.mark.parametrize("C", [2, 4, 8, 16])
+@pytest.mark.parametrize("C", [2, 4, 8, 16, 32])
 @pytest.mark.parametrize("P,pad,mode", [(40000, 0, 2), (40000, 1, 2), (40000, 2, 2), (18000, 0, 2), (40000, 0, 3)])
 def test_tiled_path_crowded_tables(C, P, pad, mode):
     """PIXEL-like shape (reference test/test_2d.py: 16x16 cells, 1e5 points): hundreds of samples per cell and the
