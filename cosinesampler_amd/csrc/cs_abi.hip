@@ -221,7 +221,7 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
     if (rc) return rc;
     const int nv = cs::unpack_nv(pb.d.C);
     dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
+    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.C, pb.d.vol);
     return launch_status();
 }
 
@@ -530,8 +530,10 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 // 3D with C in {4,8,16}: channels-last point kernels + fused row atomics, or the dense path for crowded tables
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
-    return dim == 3 && (C == 4 || C == 8 || C == 16) && rows_applies(N, C, P, vol) && N * P < ((int64_t)1 << 31) &&
-           N * vol < ((int64_t)1 << 31);   // global node ids of the fused scatter are 32-bit
+    const int mode = g_force_path.load(std::memory_order_relaxed);
+    if (mode == 1 || dim != 3 || !(C <= 4 || C == 8 || C == 16)) return false;   // C = 1..3: zero-padded to one quad
+    if (N * P >= ((int64_t)1 << 31) || N * vol >= ((int64_t)1 << 31) || vol * cpad(C) >= ((int64_t)1 << 31)) return false;
+    return mode >= 2 || N * P >= (1 << 16);   // (global node ids of the fused scatter are 32-bit)
 }
 
 // 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, one (node, channel) value per lane in cell_scatter3
@@ -542,7 +544,7 @@ constexpr int64_t kDense3MaxCells = 40000;
 bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: row atomics only
     const int64_t cells = (W + 1) * (H + 1) * (D + 1);
-    return (C == 4 || C == 8) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
+    return (C <= 4 || C == 8) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
            N * P < (int64_t)0xFFFFFFF0ll && N <= 65535;
 }
 struct Plan3Layout {
@@ -602,10 +604,10 @@ int build_plan3(const Problem &pb, const float *grid, const float *offset, void 
     return launch_status();
 }
 // floats per p-ordered row of the 3D dense path: cl::Rec without the node ids
-int dense3_row_floats(int64_t C, int stage) { return (int)((C + 8) * (stage == CS_STAGE_BBB_FUSED ? 2 : 1)); }
+int dense3_row_floats(int64_t C, int stage) { return (int)((cpad(C) + 8) * (stage == CS_STAGE_BBB_FUSED ? 2 : 1)); }
 
 size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_cl, int have_cI) {
-    size_t T = align256((size_t)N * C * vol * 4), need = 0;
+    size_t T = align256((size_t)N * cpad(C) * vol * 4), need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
@@ -613,7 +615,7 @@ size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_
 }
 size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int have_cl,
                         int have_plan, int have_cI) {
-    size_t T = align256((size_t)N * C * D * H * W * 4), need = 0;
+    size_t T = align256((size_t)N * cpad(C) * D * H * W * 4), need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
@@ -624,7 +626,7 @@ size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, i
 // resolve the channels-last table (caller's or packed into the workspace)
 int rows_cl_table(const Problem &pb, const float *input, const float *input_cl, Carve &ws, const float *&icl) {
     if (input_cl) { icl = input_cl; return CS_OK; }
-    float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+    float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     icl = buf;
     return pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
@@ -646,17 +648,18 @@ int rcl_forward(const Problem &pb, const float *input, const float *grid, const 
 template <int DIM>
 size_t rcl_lds(int C, int mode) {
     const int NC = 1 << DIM, np = mode == 2 ? 2 : 1;
-    return (size_t)256 * (C * np + NC * np + NC) * 4;
+    const int CP = (int)cpad(C);
+    return (size_t)256 * (CP * np + NC * np + NC) * 4;
 }
 // accumulator -> caller's layout
 int rcl_finish(const Problem &pb, const float *acc, float *out_grad) {
     const int nv = cs::unpack_nv(pb.d.C);
     dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.vol);
+    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, (int)cpad(pb.d.C), pb.d.vol);
     return launch_status();
 }
 int rcl_accumulator(const Problem &pb, Carve &ws, float *&acc) {
-    const int64_t T = (int64_t)pb.d.N * pb.d.C * pb.d.vol;
+    const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
     acc = (float *)ws.take((size_t)T * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     return zero_async(acc, T, pb.stream);
@@ -681,7 +684,7 @@ int dense3_prepare(const Problem &pb, const float *grid, const float *offset, co
 template <int MODE>
 int dense3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, float *grad_input) {
     unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
-    if (pb.d.C == 4) cs::dense3::cell_scatter3<1, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
+    if (pb.d.C <= 4) cs::dense3::cell_scatter3<1, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
     else cs::dense3::cell_scatter3<2, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
     return launch_status();
 }
@@ -733,7 +736,7 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
-        float *buf = (float *)ws.take((size_t)pb.d.N * pb.d.C * pb.d.vol * 4);
+        float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
         if (rc) return rc;
@@ -1036,7 +1039,7 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
                  void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, offset, output)
-    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+    if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_forward<3>(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     return run_forward<3>(pb, table_, grid, offset, output);
 }
@@ -1048,7 +1051,7 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
-    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+    if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                                workspace_bytes);
     if (rows && grad_input) {
@@ -1069,7 +1072,7 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
-    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+    if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
@@ -1092,7 +1095,7 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
-    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+    if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                           grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {
@@ -1114,7 +1117,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
-    if (rows && rows_cl_applies(3, N, C, P, pb.d.vol))
+    if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                           grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (rows) {

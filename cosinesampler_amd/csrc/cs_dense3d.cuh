@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void cell_scatter3(const float *__restrict__ r
     cell /= pl.ntx;
     const int uy = cell % pl.nty, uz = cell / pl.nty;
     const int x = ux - 1 + (a & 1), y = uy - 1 + ((a >> 1) & 1), z = uz - 1 + (a >> 2);
-    if (x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || z < 0 || z >= d.size[2] || r == 0.f) return;
-    unsafeAtomicAdd(grad_input + ((int64_t)n * C + c) * d.vol + ((int64_t)z * d.size[1] + y) * d.size[0] + x, r);
+    if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || z < 0 || z >= d.size[2] || r == 0.f) return;
+    unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + ((int64_t)z * d.size[1] + y) * d.size[0] + x, r);
 }
 
 }  // namespace dense3

@@ -522,14 +522,14 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
 // plane receives NV*4 contiguous bytes per workgroup (1 KiB at NV = 256; 64 nodes measured 3.6 TB/s).
 __host__ __device__ constexpr int unpack_nv(int C) { return C > 32 ? 128 : 256; }   // tile stays under 64 KiB of LDS
 __global__ __launch_bounds__(256) void unpack_channels_last(const float *__restrict__ in, float *__restrict__ out,
-                                                            int C, int64_t vol) {
+                                                            int C, int CP, int64_t vol) {   // CP: channels of `in` (padded)
     extern __shared__ float tile[];  // [NV][C+1]
     const int NV = unpack_nv(C);
     const int n = blockIdx.y;
     const int64_t v0 = (int64_t)blockIdx.x * NV;
     for (int idx = threadIdx.x; idx < C * NV; idx += 256) {
         int v = idx / C, c = idx - v * C;
-        tile[v * (C + 1) + c] = (v0 + v < vol) ? in[((int64_t)n * vol + v0 + v) * C + c] : 0.0f;
+        tile[v * (C + 1) + c] = (v0 + v < vol) ? in[((int64_t)n * vol + v0 + v) * CP + c] : 0.0f;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < C * NV; idx += 256) {

@@ -17,15 +17,20 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
     return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ float4 load_quad(const float *src, int64_t P) {
-    return make_float4(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + P),
-                       __builtin_nontemporal_load(src + 2 * P), __builtin_nontemporal_load(src + 3 * P));
+// the 4 channels of a quad of a channel-major stream; cv = how many of them exist (C = 1..3 runs zero-padded)
+__device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
+    float4 r;
+    r.x = __builtin_nontemporal_load(src);
+    r.y = cv > 1 ? __builtin_nontemporal_load(src + P) : 0.0f;
+    r.z = cv > 2 ? __builtin_nontemporal_load(src + 2 * P) : 0.0f;
+    r.w = cv > 3 ? __builtin_nontemporal_load(src + 3 * P) : 0.0f;
+    return r;
 }
-__device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o) {
+__device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o, int cv) {
     __builtin_nontemporal_store(o.x, dst);
-    __builtin_nontemporal_store(o.y, dst + P);
-    __builtin_nontemporal_store(o.z, dst + 2 * P);
-    __builtin_nontemporal_store(o.w, dst + 3 * P);
+    if (cv > 1) __builtin_nontemporal_store(o.y, dst + P);
+    if (cv > 2) __builtin_nontemporal_store(o.z, dst + 2 * P);
+    if (cv > 3) __builtin_nontemporal_store(o.w, dst + 3 * P);
 }
 
 // node rows of one channel quad; zero-padded nodes read row 0 and are masked
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     float W[NC];
     sm.weights(W);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float *o = out + (int64_t)sm.n * C * d.P + sm.p;
+    float *o = out + (int64_t)sm.n * d.C * d.P + sm.p;   // d.C: the caller's channel count (C is the padded one)
     float4 v[CQ][NC];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
         float4 acc = zero4();
 #pragma unroll
         for (int a = 0; a < NC; ++a) acc = fma4(W[a], v[q][a], acc);
-        store_quad(o + (int64_t)(4 * q) * d.P, d.P, acc);
+        store_quad(o + (int64_t)(4 * q) * d.P, d.P, acc, d.C - 4 * q);
     }
 }
 
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
     float4 v[CQ][NC], g[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
-        g[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P);
+        g[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
         gather_quad<DIM, CQ>(tab, sm, q, v[q]);
     }
 #pragma unroll
@@ -221,10 +226,10 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
     const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    float *ggo = ggOut + (int64_t)sm.n * C * d.P + sm.p;
+    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
-        float4 g = load_quad(go + (int64_t)(4 * q) * d.P, d.P);
+        float4 g = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
         if (SCATTER) *reinterpret_cast<float4 *>(rec + 4 * q) = g;
         float4 v[NC];
         gather_quad<DIM, CQ>(tab, sm, q, v);
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
                 }
             }
         }
-        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o);
+        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o, d.C - 4 * q);
     }
     float *gg = gGrid + ((int64_t)sm.n * d.P + sm.p) * DIM;
 #pragma unroll
@@ -314,9 +319,9 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
         const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
-            *reinterpret_cast<float4 *>(rec + 4 * q) = load_quad(go + (int64_t)(4 * q) * d.P, d.P);
+            *reinterpret_cast<float4 *>(rec + 4 * q) = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
             float4 h = zero4();
-            if (hO) h = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P);
+            if (hO) h = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
             *reinterpret_cast<float4 *>(rec + C + 4 * q) = h;
         }
 #pragma unroll
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
         }
     }
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float *ggo = ggOut + (int64_t)sm.n * C * d.P + sm.p;
+    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     float4 v[CQ][NC];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
         float4 o = zero4();
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fma4(Em[a], v[q][a], o);
-        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o);
+        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o, d.C - 4 * q);
     }
     }
     if (SCATTER) {

@@ -52,7 +52,7 @@ def test_loader_binds_and_reports_errors_without_gpu():
     assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == 2 * T3  # + channels-last copy
     assert lib.cs_workspace_bytes(3, 0, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == 0
     assert lib.cs_pack_bytes(3, 8, 8, 128, 128, 128, 1 << 19) == T3
-    assert lib.cs_workspace_bytes(2, 3, 16, 32, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 32 * 256 * 256 * 4
+    assert lib.cs_workspace_bytes(2, 3, 16, 64, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 64 * 256 * 256 * 4
     assert lib.cs_workspace_bytes(2, 1, 16, 5, 1, 256, 256, 1 << 20, 0, 0, 0) == 0
     assert lib.cs_workspace_bytes(2, 1, 1, 16, 1, 32, 32, 1024, 0, 0, 0) == 0
     # argument validation happens before any device work: callable without a GPU

@@ -129,7 +129,8 @@ def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
 
 
 ROW_CASES = [(3, 8, 0, 0, True, True), (3, 8, 2, 0, True, True), (3, 2, 1, 1, False, False), (3, 16, 2, 2, True, False),
-             (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False)]
+             (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False),
+             (3, 3, 0, 0, True, True), (3, 1, 2, 1, True, False)]   # 3D with 1..3 channels: one zero-padded quad
 
 
 class _Shared(object):
