@@ -247,8 +247,18 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
     return S >= kTiledMinSamples;
 }
 
+constexpr int64_t PLAN_WGS = 1024;   // 2048 and 4096 measured the same
+// samples per plan workgroup: enough workgroups to balance the chip (the plan kernels are bound by LDS atomics per
+// CU), few enough that the per-chunk histograms (chunks x bins words) stay small
+int plan_chunk(int64_t N, int64_t P, int64_t bins) {
+    if (bins > 12288) return 4 * tl::CHUNK;
+    int64_t want = (N * P + PLAN_WGS - 1) / PLAN_WGS;            // samples per workgroup for ~PLAN_WGS workgroups
+    want = (want + 255) / 256 * 256;
+    return (int)std::min<int64_t>(std::max<int64_t>(want, 1024), tl::CHUNK);
+}
+
 struct PlanLayout {
-    int ntx, nty, ntiles, chunks, dense;
+    int ntx, nty, ntiles, chunks, chunk, dense;
     size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, bytes;
 };
 
@@ -268,7 +278,8 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     L.ntx = L.dense ? (int)(W + 1) : (int)((W + 1 + tl::TX - 1) / tl::TX);
     L.nty = L.dense ? (int)(H + 1) : (int)((H + 1 + tl::TY - 1) / tl::TY);
     L.ntiles = L.ntx * L.nty;
-    L.chunks = (int)((P + tl::CHUNK - 1) / tl::CHUNK);
+    L.chunk = plan_chunk(N, P, L.ntiles);
+    L.chunks = (int)((P + L.chunk - 1) / L.chunk);
     int64_t S = N * P;
     size_t o = 0;
     L.off_sorted = o;     o += align256((size_t)S * 4);
@@ -303,7 +314,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.nty = L.nty;
     p.ntiles = L.ntiles;
     p.chunks = L.chunks;
-    p.chunk = tl::CHUNK;
+    p.chunk = L.chunk;
     p.dense = L.dense;
     return p;
 }
@@ -556,7 +567,7 @@ Plan3Layout plan3_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) 
     L.ntx = (int)(W + 1);
     L.nty = (int)(H + 1);
     L.ntiles = (int)((W + 1) * (H + 1) * (D + 1));
-    L.chunk = L.ntiles > 12288 ? 4 * tl::CHUNK : tl::CHUNK;   // fewer, larger chunks when a histogram is 50-160 KiB
+    L.chunk = plan_chunk(N, P, L.ntiles);   // fewer, larger chunks when a histogram is 50-160 KiB
     L.chunks = (int)((P + L.chunk - 1) / L.chunk);
     size_t o = 0;
     L.off_sorted = o;     o += align256((size_t)N * P * 4);

@@ -42,7 +42,7 @@ namespace tiled {
 
 constexpr int TX = 16, TY = 16;            // cells per tile
 constexpr int CELLS = TX * TY;             // 256 -> local cell id fits a byte
-constexpr int CHUNK = 16384;               // samples per plan workgroup
+constexpr int CHUNK = 16384;               // samples per plan workgroup, at most (Plan::chunk)
 
 struct Plan {
     uint32_t *sorted;      // [S]  sorted position (by n, tile, cell) -> sample id n*P+p; only the first
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void plan_count(const float *__restrict__ grid
     for (int b = threadIdx.x; b < pl.ntiles; b += 256) hist[b] = 0;
     __syncthreads();
     const float off = offset[n];
-    const int64_t p0 = (int64_t)chunk * CHUNK;
-    for (int i = threadIdx.x; i < CHUNK; i += 256) {
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
             float2 g = *reinterpret_cast<const float2 *>(grid + ((int64_t)n * d.P + p) * 2);
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
     for (int b = threadIdx.x; b < pl.ntiles; b += 256) cursor[b] = tb[b] + excl[b];
     __syncthreads();
     const float off = offset[n];
-    const int64_t p0 = (int64_t)chunk * CHUNK;
-    for (int i = threadIdx.x; i < CHUNK; i += 256) {
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
             int64_t s = (int64_t)n * d.P + p;
