@@ -425,7 +425,7 @@ def test_tiled_path_crowded_tables(C, P, pad, mode):
         assert_close(got[k], want[k], "crowded C=%d P=%d pad=%d: %s" % (C, P, pad, k))
 
 
-@pytest.mark.parametrize("shape", [(4, 16, 48, 30000), (96, 4, 16, 40000), (2, 3, 20, 3000)])
+@pytest.mark.parametrize("shape", [(4, 16, 48, 30000), (96, 4, 16, 40000), (2, 3, 20, 3000), (3, 32, 40, 30000)])
 def test_stages_can_be_captured_in_a_hip_graph(shape):
     """Nothing in a stage allocates through HIP, synchronises or touches the host, so a whole
     step -- channels-last copy, plan, forward and the three backward stages -- can be captured into a HIP graph and
