@@ -364,7 +364,7 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     if (stage == CS_STAGE_FORWARD) return need;
     if (!have_plan) need += plan_layout(N, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? 2 * CP + 8 : CP + 4) * 4);   // fat rows
+    need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? tl::row2((int)CP) : tl::row1((int)CP)) * 4);   // fat rows
     return need;
 }
 
@@ -444,16 +444,16 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
                                           gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
     // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
-    float *fat = (float *)ws.take((size_t)pb.d.S * (cpad(pb.d.C) + 4) * 4);
+    float *fat = (float *)ws.take((size_t)pb.d.S * tl::row1((int)cpad(pb.d.C)) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 4), pb.stream>>>(
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
                                       gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
@@ -478,12 +478,12 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     }
     float *fat = nullptr;
     if (gInput) {
-        fat = (float *)ws.take((size_t)pb.d.S * (cpad(pb.d.C) + 4) * 4);
+        fat = (float *)ws.take((size_t)pb.d.S * tl::row1((int)cpad(pb.d.C)) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
-    const size_t shm = q_lds((int)cpad(pb.d.C) + 4, 12);
+    const size_t shm = q_lds(tl::row1((int)cpad(pb.d.C)), 12);
     if (!gInput) {
         if (cIcl) {
             CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
@@ -513,12 +513,12 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *fat = (float *)ws.take((size_t)pb.d.S * (2 * cpad(pb.d.C) + 8) * 4);
+    float *fat = (float *)ws.take((size_t)pb.d.S * tl::row2((int)cpad(pb.d.C)) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
     if (hO) {
-        const size_t shm = q_lds(2 * (int)cpad(pb.d.C) + 8, 0);   // 80 KiB at 32 channels
+        const size_t shm = q_lds(tl::row2((int)cpad(pb.d.C)), 0);   // 80 KiB at 32 channels
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
             rc = allow_lds(tl::point_bbb<KERNEL, CQ, true>, shm);
             if (!rc) tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
@@ -529,7 +529,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         if (rc) return rc;
         return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds((int)cpad(pb.d.C) + 4, 0), pb.stream>>>(
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;

@@ -42,6 +42,10 @@ namespace tiled {
 
 constexpr int TX = 16, TY = 16;            // cells per tile
 constexpr int CELLS = TX * TY;             // 256 -> local cell id fits a byte
+// floats per fat row: [payload (C) | 4 coefficients], third backward [2 payloads | 2 x 4 coefficients]
+// (80-byte rows padded and aligned to 128 bytes measured slower: +0.11-0.16 ms per stage, profiles/round1_ablation.txt)
+__host__ __device__ constexpr int row1(int C) { return C + 4; }
+__host__ __device__ constexpr int row2(int C) { return 2 * C + 8; }
 constexpr int CHUNK = 16384;               // samples per plan workgroup, at most (Plan::chunk)
 
 struct Plan {
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
                                                       const float *__restrict__ grid, const float *__restrict__ offset,
                                                       float *__restrict__ fat, float *__restrict__ grad_grid,
                                                       Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 4, CO = 4 * 64;
+    constexpr int C = 4 * CQ, STRIDE = row1(C), CO = 4 * 64;
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC + CO);
     float *rec = stage + 64 * STRIDE;
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
                                                   const float *__restrict__ gOut, const float *__restrict__ offset,
                                                   float *__restrict__ fat, float *__restrict__ gGrid,
                                                   float *__restrict__ ggOut, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = C + 4, CO = 12 * 64;
+    constexpr int C = 4 * CQ, STRIDE = row1(C), CO = 12 * 64;
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC + CO);
     float *rec = stage + 64 * STRIDE;
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
                                                    const float *__restrict__ hG, const float *__restrict__ hO,
                                                    const float *__restrict__ offset, float *__restrict__ fat,
                                                    float *__restrict__ ggOut, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = TWO ? 2 * C + 8 : C + 4, EOFF = TWO ? 2 * C : C;
+    constexpr int C = 4 * CQ, STRIDE = TWO ? row2(C) : row1(C), EOFF = TWO ? 2 * C : C;
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC);
     float *rec = stage + 64 * STRIDE;
@@ -740,7 +744,7 @@ template <int CQ, bool TWO>
 __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fat, Plan pl,
                                                     float *__restrict__ grad_input, Dims d) {
     constexpr int C = 4 * CQ;
-    constexpr int STRIDE = TWO ? 2 * C + 8 : C + 4;
+    constexpr int STRIDE = TWO ? row2(C) : row1(C);
     constexpr int SEGW = CQ;                   // cells per walker
     constexpr int NSEG = TX / SEGW;            // walkers per cell row
     constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
@@ -868,7 +872,7 @@ template <int CQ, bool TWO>
 __global__ __launch_bounds__(256) void cell_scatter(const float *__restrict__ fat, Plan pl,
                                                     float *__restrict__ grad_input, Dims d) {
     constexpr int C = 4 * CQ, NV = 4 * C;
-    constexpr int STRIDE = TWO ? 2 * C + 8 : C + 4;
+    constexpr int STRIDE = TWO ? row2(C) : row1(C);
     const int64_t bucket = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bucket >= (int64_t)d.N * pl.ntiles) return;
     const uint32_t b0 = pl.tile_begin[bucket], b1 = pl.tile_begin[bucket + 1];
