@@ -548,14 +548,14 @@ bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
 }
 
 // 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, one (node, channel) value per lane in cell_scatter3
-// (C <= 8), and enough samples per cell for a wave per cell to pay: measured with 32^3-cell tables, 28 samples per cell
+// (two at 16 channels), and enough samples per cell for a wave per cell to pay: measured with 32^3-cell tables, 28 samples per cell
 // 1.9 vs 4.9 ms per stage, 2.8 per cell 1.47 vs 1.26 ms -- the threshold is 8
 // the cell histogram of the 3D plan lives in LDS: 160 KiB per workgroup on gfx950 = 40960 bins (a 33^3-cell table fits)
 constexpr int64_t kDense3MaxCells = 40000;
 bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: row atomics only
     const int64_t cells = (W + 1) * (H + 1) * (D + 1);
-    return (C <= 4 || C == 8) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
+    return (C <= 4 || C == 8 || C == 16) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
            N * P < (int64_t)0xFFFFFFF0ll && N <= 65535;
 }
 struct Plan3Layout {
@@ -695,8 +695,7 @@ int dense3_prepare(const Problem &pb, const float *grid, const float *offset, co
 template <int MODE>
 int dense3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, float *grad_input) {
     unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
-    if (pb.d.C <= 4) cs::dense3::cell_scatter3<1, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
-    else cs::dense3::cell_scatter3<2, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d);
+    CS_DISPATCH_CQ(pb.d.C, (cs::dense3::cell_scatter3<CQ, MODE><<<nbk, 256, 0, pb.stream>>>(rows, pl, grad_input, pb.d)));
     return launch_status();
 }
 

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void cell_scatter3(const float *__restrict__ r
                                                      float *__restrict__ grad_input, Dims d) {
     using R = cl::Rec<3, CQ, MODE>;
     constexpr int C = 4 * CQ, NC = 8, NV = NC * C;
-    static_assert(NV <= 64, "one (node, channel) value per lane");
+    static_assert(NV <= 128, "at most two (node, channel) values per lane");
     const int64_t bucket = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bucket >= (int64_t)d.N * pl.ntiles) return;
     const uint32_t b0 = pl.tile_begin[bucket], b1 = pl.tile_begin[bucket + 1];
@@ -125,32 +125,40 @@ __global__ __launch_bounds__(256) void cell_scatter3(const float *__restrict__ r
                 v[a * C + c] = t;
             }
     }
-    // halving exchange (as tiled::cell_scatter): lane l ends with value l >> (6 - log2 NV)
-    int m = 32;
+    // halving exchange (as tiled::cell_scatter): six steps leave NV / 64 fully reduced values per lane (C = 16: values
+    // 2 l and 2 l + 1 on lane l); with NV < 64 the last steps are plain butterflies and 64 / NV lanes share a value
+    constexpr int VALS = NV >= 64 ? NV / 64 : 1, SHARE = NV >= 64 ? 1 : 64 / NV;
+    int cur = NV;
 #pragma unroll
-    for (int half = NV / 2; half >= 1; half >>= 1) {
-        const bool up = (lane & m) != 0;
+    for (int m = 32; m >= 1; m >>= 1) {
+        if (cur > VALS) {
+            const int half = cur / 2;
+            const bool up = (lane & m) != 0;
 #pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float lo = v[i], hi = v[i + half];
-            const float got = __shfl_xor(up ? lo : hi, m);
-            v[i] = (up ? hi : lo) + got;
+            for (int i = 0; i < half; ++i) {
+                const float lo = v[i], hi = v[i + half];
+                const float got = __shfl_xor(up ? lo : hi, m);
+                v[i] = (up ? hi : lo) + got;
+            }
+            cur = half;
+        } else {
+            v[0] += __shfl_xor(v[0], m);
         }
-        m >>= 1;
     }
-    float r = v[0];
-    for (; m >= 1; m >>= 1) r += __shfl_xor(r, m);
-    constexpr int SHARE = 64 / NV;
     if (lane % SHARE) return;
-    const int idx = lane / SHARE, a = idx / C, c = idx % C;
     const int n = (int)(bucket / pl.ntiles);
     int cell = (int)(bucket - (int64_t)n * pl.ntiles);
     const int ux = cell % pl.ntx;
     cell /= pl.ntx;
     const int uy = cell % pl.nty, uz = cell / pl.nty;
-    const int x = ux - 1 + (a & 1), y = uy - 1 + ((a >> 1) & 1), z = uz - 1 + (a >> 2);
-    if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || z < 0 || z >= d.size[2] || r == 0.f) return;
-    unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + ((int64_t)z * d.size[1] + y) * d.size[0] + x, r);
+#pragma unroll
+    for (int jv = 0; jv < VALS; ++jv) {
+        const int idx = (lane / SHARE) * VALS + jv, a = idx / C, c = idx % C;
+        const int x = ux - 1 + (a & 1), y = uy - 1 + ((a >> 1) & 1), z = uz - 1 + (a >> 2);
+        const float r = v[jv];
+        if (c >= d.C || x < 0 || x >= d.size[0] || y < 0 || y >= d.size[1] || z < 0 || z >= d.size[2] || r == 0.f) continue;
+        unsafeAtomicAdd(grad_input + ((int64_t)n * d.C + c) * d.vol + ((int64_t)z * d.size[1] + y) * d.size[0] + x, r);
+    }
 }
 
 }  // namespace dense3

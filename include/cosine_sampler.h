@@ -97,7 +97,7 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                     int padding_mode, int align_corners, int multicell, void *stream);
 
-/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C in {4,8},
+/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C in {1..4,8,16},
  * P >= 8 cells: the reference's test_3d.py shapes): samples binned by cell.  cs3d_plan_bytes returns 0 otherwise. */
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
