@@ -17,6 +17,16 @@ def test_enums_follow_reference():
     assert kernel_enum("cubic") is None
 
 
+def test_mixed_suffix_is_an_extension_of_the_kernel_names():
+    """'+mixed' (not in the reference) ORs CS_KERNEL_EXACT_MIXED into the enum; every reference name is unchanged."""
+    from cosinesampler_amd import ops
+    assert ops.EXACT_MIXED == 0x100
+    for name, base in (("cosine", 0), ("bilinear", 1), ("trilinear", 1), ("smooth-step", 2)):
+        assert kernel_enum(name) == base
+        assert kernel_enum(name + "+mixed") == base | ops.EXACT_MIXED
+    assert kernel_enum("cosine+exact") is None and kernel_enum("mixed") is None
+
+
 def test_offset_bits_match_reference_construction():
     for N in (1, 3, 16, 96):
         assert torch.equal(multicell_offset(N, True, "cpu"), torch.linspace(0, 1 - (1 / N), N))
