@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the sample-sharded path.  Each rank runs the op on its slice of the
+"""CPU, world_size 2 and 3, gloo: the sample-sharded path.  Each rank runs the op on its slice of the
 points (kernels replaced by the CPU oracle), grad_input partial sums meet in ONE all-reduce, and
 everything must equal the unsharded run.  The GPU job uses backend "nccl" (= RCCL) instead."""
 import os
@@ -76,16 +76,17 @@ def _worker(rank, world, port, d, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d", [2, 3])
-def test_sharded_equals_unsharded_world2(d):
+@pytest.mark.parametrize("d,world", [(2, 2), (3, 2), (2, 3)])
+def test_sharded_equals_unsharded(d, world):
+    """world 2 in 2D and 3D; world 3 with 101 points: shards of 34 / 34 / 33."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, d, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=5) for _ in range(2))
-    assert res == [(0, True), (1, True)]
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]
