@@ -27,6 +27,22 @@ def test_mixed_suffix_is_an_extension_of_the_kernel_names():
     assert kernel_enum("cosine+exact") is None and kernel_enum("mixed") is None
 
 
+def test_expanded_cotangents_are_left_alone():
+    """ops.keep_expanded: an n-expanded view over one contiguous block stays a view (the kernels take its stride);
+    every other non-contiguous layout is made contiguous, as the reference's .contiguous() would."""
+    from cosinesampler_amd import ops
+    base = torch.rand(1, 4, 1, 50)
+    e = base.expand(6, 4, 1, 50)
+    assert ops.keep_expanded(e) is e and e.stride(0) == 0
+    c = torch.rand(6, 4, 1, 50)
+    assert ops.keep_expanded(c) is c
+    t = torch.rand(4, 6, 1, 50).transpose(0, 1)                  # channel-strided: not supported in place
+    assert ops.keep_expanded(t).is_contiguous() and torch.equal(ops.keep_expanded(t), t)
+    inner = torch.rand(1, 4, 1, 100)[..., ::2].expand(6, 4, 1, 50)   # expanded, but the block itself is strided
+    assert ops.keep_expanded(inner).is_contiguous()
+    assert ops.keep_expanded(None) is None
+
+
 def test_offset_bits_match_reference_construction():
     for N in (1, 3, 16, 96):
         assert torch.equal(multicell_offset(N, True, "cpu"), torch.linspace(0, 1 - (1 / N), N))
