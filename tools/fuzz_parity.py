@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: every stage on the GPU (through the C ABI, every execution path) against the CPU oracle on
+random small problems -- shapes with ragged tails, tiny tables, all paddings / kernels / flags, out-of-range points.
+    python tools/fuzz_parity.py [cases] [seed]
+Prints one line per failure and a summary; exit code 1 if anything differed by more than 1e-5 (relative to the
+largest reference magnitude of the tensor, as tests/helpers.py)."""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+
+from cosinesampler_amd import multicell_offset, ops
+from oracle import cs_oracle
+
+DEV = torch.device("cuda", 0)
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = random.Random(seed)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    den = float(b.abs().max())
+    return float((a - b).abs().max()) / (den if den > 0 else 1.0)
+
+
+def run(mod, t, off, pad, align, ke, mc, dev, shared):
+    x = {k: v.to(dev) for k, v in t.items()}
+    off = off.to(dev)
+    kw = {}
+    if shared:
+        kw["ctx"] = ops.StepContext()
+    r = {}
+    r["out"] = mod.forward(x["inp"], x["grid"], off, pad, align, ke, mc, **kw)
+    r["gI"], r["gG"] = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, True, ke, mc, **kw)
+    r["gG0"] = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, False, ke, mc, **kw)[1]
+    r["bbI"], r["bbG"], r["bbO"] = mod.backward_backward(x["cI"], x["cG"], x["inp"], x["grid"], x["gOut"], off, pad, align,
+                                                         True, ke, mc, **kw)
+    r["bI0"], r["bG0"], r["bO0"] = mod.backward_backward(None, x["cG"], x["inp"], x["grid"], x["gOut"], off, pad, align,
+                                                         False, ke, mc, **kw)
+    r["k4I"], r["k4O"] = mod.backward_backward_backward(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], off, pad, align,
+                                                        True, ke, mc, **kw)
+    r["fI"], r["fO"] = mod.bbb_fused(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], off, pad, align, ke, mc, **kw)
+    return r
+
+
+bad = 0
+for case in range(cases):
+    d = rng.choice([2, 2, 3])
+    C = rng.choice([1, 2, 3, 4, 5, 8, 16, 32] if d == 2 else [1, 2, 3, 4, 8, 16, 6])
+    N = rng.choice([1, 2, 3, 5])
+    sp = tuple(rng.choice([2, 3, 5, 16, 17, 18, 33, 40]) for _ in range(d)) if d == 2 else \
+        tuple(rng.choice([2, 3, 5, 8, 9, 16]) for _ in range(d))
+    P = rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3001, 5000, 20000])
+    pad, align, ke, mc = rng.choice([0, 1, 2]), rng.choice([True, False]), rng.choice([0, 1, 2]), rng.choice([True, False])
+    force = rng.choice([0, 1, 2, 2, 2, 3])
+    shared = rng.choice([True, False])
+    g = torch.Generator().manual_seed(seed * 100003 + case)
+    inp = torch.rand((N, C) + sp, generator=g)
+    spread = rng.choice([0.9, 1.0, 1.3])
+    grid = torch.rand((N,) + (1,) * (d - 1) + (P, d), generator=g) * (2 * spread) - spread
+    if P >= 3:
+        grid.view(N, P, d)[:, 0] = -1.0
+        grid.view(N, P, d)[:, 1] = 1.0
+    osh = (N, C) + (1,) * (d - 1) + (P,)
+    t = dict(inp=inp, grid=grid, gOut=torch.randn(osh, generator=g), cI=torch.randn(inp.shape, generator=g),
+             cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g), hO=torch.randn(osh, generator=g))
+    off = multicell_offset(N, mc, "cpu")
+    want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False)
+    ops.force_path(force)
+    try:
+        got = run(ops, t, off, pad, align, ke, mc, DEV, shared)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    errs = {k: rel(got[k], want[k]) for k in want}
+    worst = max(errs, key=errs.get)
+    if not all(torch.isfinite(v).all() for v in got.values()) or errs[worst] > 1e-5:
+        bad += 1
+        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s -> %s %.3e"
+              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, worst, errs[worst]), flush=True)
+    elif case % 25 == 0:
+        print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d) worst %s %.1e" % (case, d, C, sp, P, force, worst, errs[worst]),
+              flush=True)
+print("%d cases, %d failures" % (cases, bad))
+sys.exit(1 if bad else 0)
