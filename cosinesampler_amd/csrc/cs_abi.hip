@@ -183,6 +183,7 @@ bool rows_applies(int64_t N, int64_t C, int64_t P, int64_t vol) {
     if (mode == 1) return false;
     if (log2_exact(C) < 1) return false;                       // C = 1: rows are single floats, nothing to gain
     if (N * P * C >= ((int64_t)1 << 40) || vol * C >= ((int64_t)1 << 31)) return false;
+    if (N > 65535) return false;                               // unpack_channels_last launches with gridDim.y = N
     if (mode == 2) return true;
     return N * P >= (1 << 16);
 }
@@ -206,6 +207,7 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
     int rc = zero_async(acc, T, pb.stream);
     if (rc) return rc;
     const int logC = log2_exact(pb.d.C);
+    if (logC < 0 || pb.d.N > 65535) return CS_ERR_UNSUPPORTED;   // channel masks are shifts; gridDim.y = N in the unpack
     const bool pair = pb.d.C <= 8;   // node rows under 64 bytes go in x-neighbour pairs (same request rate, half the requests)
     const int64_t lanes = pb.d.S << (logC + (pair ? 1 : 0));
     if ((lanes + kBlock - 1) / kBlock > (int64_t)INT32_MAX) return CS_ERR_UNSUPPORTED;
@@ -226,7 +228,7 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiled path (2D, C in {4,8,16})
+// tiled path (2D, C in {1..4, 8, 16, 32})
 // ------------------------------------------------------------------------------------------------
 constexpr int64_t kTiledMinSamples = 1 << 16;  // below this the launch count matters more than atomics
 
@@ -430,8 +432,15 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
+#ifndef CS_FWD3
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
+#else   // experiment (tools/kbench.hip): LDS-DMA gathers + register stores; faster only with warm caches
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
+        constexpr int NB = 2 < CQ ? 2 : CQ;
+        tl::point_forward3<KERNEL, CQ, NB><<<point_grid(pb), kBlock, tl::f3_lds<CQ, NB>(), pb.stream>>>(pr.icl, grid, offset, output, pb.d, pb.f);
+    }));
+#endif
     return launch_status();
 }
 
@@ -538,12 +547,13 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3D with C in {4,8,16}: channels-last point kernels + fused row atomics, or the dense path for crowded tables
+// 3D with C in {1..4, 8, 16}: channels-last point kernels + fused row atomics, or the dense path for crowded tables
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     const int mode = g_force_path.load(std::memory_order_relaxed);
     if (mode == 1 || dim != 3 || !(C <= 4 || C == 8 || C == 16)) return false;   // C = 1..3: zero-padded to one quad
     if (N * P >= ((int64_t)1 << 31) || N * vol >= ((int64_t)1 << 31) || vol * cpad(C) >= ((int64_t)1 << 31)) return false;
+    if (N > 65535) return false;                               // pack / unpack launch with gridDim.y = N
     return mode >= 2 || N * P >= (1 << 16);   // (global node ids of the fused scatter are 32-bit)
 }
 
@@ -981,7 +991,8 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     // exact + grad_out_input: the grad_out_input -> grad_grid term is only in the direct kernel (run_bb)
-    const bool via_rows = rows || (tiled && pb.f.exact && grad_out_input);
+    // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
+    const bool via_rows = rows || (tiled && pb.f.exact && grad_out_input && log2_exact(C) >= 1 && N <= 65535);
     if (tiled && !via_rows)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);

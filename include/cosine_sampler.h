@@ -31,7 +31,7 @@
  *     offset, sizes and flags.  The library cannot check that they match (they live in device
  *     memory and nothing here synchronises): passing a stale one is undefined behaviour.  When
  *     NULL, a stage that wants them builds them inside `workspace` (cs_workspace_bytes accounts
- *     for it).  Problems outside the fast path (3D, C not in {4,8,16}, tiny S) ignore both.
+ *     for it).  Problems outside the fast paths (channel counts other than 1..4, 8, 16 [, 32 in 2D], tiny S) ignore both.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
  *   - Thread-safe and re-entrant: the library keeps no mutable global state (the one exception is

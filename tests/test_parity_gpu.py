@@ -193,6 +193,32 @@ def test_second_backward_without_table_gradient(d, C, force, with_cI):
         ops.force_path(0)
 
 
+@pytest.mark.parametrize("C", [1, 3, 4, 16])
+@pytest.mark.parametrize("force", [0, 2])
+def test_exact_mixed_second_backward_with_grad_out_input(C, force):
+    """'+mixed' second backward WITH a grad_out_input while d/d input is wanted (a double backward through grad_input):
+    the tiled 2D path hands this call to the direct kernel for grad_grid and to the row-atomic scatter for grad_input,
+    which exists only for power-of-two channel counts >= 2 -- C = 1 and 3 must stay on the direct kernel (round-1
+    advisor finding: they reached row_scatter with a channel shift of -1, out of bounds).  N*P >= 2^16 so that the
+    fast paths are chosen without forcing; the direct kernels (force = 1) are the reference."""
+    N, P = 2, 40000
+    t = _case(2, N, C, (33, 29), P, seed=4100 + C, spread=1.1)
+    off = offsets(N, True).to(DEV)
+    inp, grid, gO, cG, cI = (_g(t[k]) for k in ("inp", "grid", "gOut", "cG", "cI"))
+    ke = 0 | ops.EXACT_MIXED
+    ops.force_path(1)
+    try:
+        want = ops.backward_backward(cI, cG, inp, grid, gO, off, 0, True, True, ke, True)
+        ops.force_path(force)
+        got = ops.backward_backward(cI, cG, inp, grid, gO, off, 0, True, True, ke, True, ctx=ops.StepContext())
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for a, b, nm in zip(got, want, ("grad_input", "grad_grid", "grad_grad_out")):
+        assert torch.isfinite(a).all()
+        assert_close(a, b, "exact-mixed bb with grad_out_input C=%d force=%d: %s" % (C, force, nm))
+
+
 @pytest.mark.parametrize("d,C,force", [(2, 16, 2), (2, 8, 2), (2, 3, 0), (2, 32, 2), (3, 8, 2), (3, 5, 0), (3, 2, 2)])
 def test_expanded_cotangents_equal_contiguous_ones(d, C, force):
     """cs_cotangent_layout: grad_output / grad_out_ggout expanded along n (stride 0, what the backward of PIXEL's
