@@ -14,7 +14,8 @@ _c_sz = ctypes.c_size_t
 
 class CotangentLayout(ctypes.Structure):
     """cs_cotangent_layout (include/cosine_sampler.h): n-strides, in elements, of grad_output / grad_out_ggout."""
-    _fields_ = [("grad_output_stride_n", ctypes.c_int64), ("grad_out_ggout_stride_n", ctypes.c_int64)]
+    _fields_ = [("grad_output_stride_n", ctypes.c_int64), ("grad_out_ggout_stride_n", ctypes.c_int64),
+                ("sorted_grad_output_valid", ctypes.c_int32), ("sorted_grad_out_grid_valid", ctypes.c_int32)]
 
 
 # name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, [layout*, backward stages only],
@@ -30,7 +31,8 @@ EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_pack_
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 6
+ABI_VERSION = 7
+STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 

@@ -10,6 +10,7 @@
 #include "cs_kernels_direct.cuh"
 #include "cs_points_cl.cuh"
 #include "cs_tiled.cuh"
+#include "cs_sorted.cuh"
 #include "cs_dense3d.cuh"
 
 namespace {
@@ -17,6 +18,7 @@ namespace {
 using cs::Dims;
 using cs::Flags;
 namespace tl = cs::tiled;
+namespace so = cs::sorted;
 
 constexpr int kBlock = 256;
 std::atomic<int> g_force_path{0};  // cs_debug_force_path
@@ -184,7 +186,7 @@ bool rows_applies(int64_t N, int64_t C, int64_t P, int64_t vol) {
     if (log2_exact(C) < 1) return false;                       // C = 1: rows are single floats, nothing to gain
     if (N * P * C >= ((int64_t)1 << 40) || vol * C >= ((int64_t)1 << 31)) return false;
     if (N > 65535) return false;                               // unpack_channels_last launches with gridDim.y = N
-    if (mode == 2) return true;
+    if (mode >= 2) return true;
     return N * P >= (1 << 16);
 }
 
@@ -245,7 +247,7 @@ bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
     if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
     if (N > 65535 || H * W * C >= ((int64_t)1 << 31)) return false;   // gridDim.y = N; 32-bit node offsets
     if (P > ((int64_t)1 << 24)) return false;                          // plan keys pack (p << 8) | cell
-    if (mode == 2 || mode == 3) return true;
+    if (mode >= 2) return true;
     return S >= kTiledMinSamples;
 }
 
@@ -544,6 +546,235 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         if (rc) return rc;
         return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sorted path (cs_sorted.cuh): the tiled problems whose cell histogram fits the LDS as 16-bit counters and whose
+// tables are not crowded.  Same prepared objects as the tiled path; the plan blob has its own layout.
+// ------------------------------------------------------------------------------------------------
+bool sorted_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
+    if (g_force_path.load(std::memory_order_relaxed) == 4) return false;   // testing: round 1's fat-row path
+    if (!tiled_applies(dim, N, C, H, W, P) || dense_applies(N, H, W, P)) return false;
+    const int64_t bins = (W + 1) * (H + 1);
+    return bins <= so::P2_MAX_BINS && N * bins < (int64_t)INT32_MAX;
+}
+
+struct Plan2Layout {
+    int bx, by, bins, words, chunks, chunk, ntx, nty;
+    size_t off_rank, off_coord, off_cell_begin, off_cnt, off_excl, off_totals, off_bsum, off_G, off_cG, bytes;
+};
+Plan2Layout plan2_layout(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
+    Plan2Layout L;
+    L.bx = (int)(W + 1);
+    L.by = (int)(H + 1);
+    L.bins = L.bx * L.by;
+    L.words = (L.bins + 1) / 2;
+    L.ntx = (L.bx + tl::TX - 1) / tl::TX;
+    L.nty = (L.by + tl::TY - 1) / tl::TY;
+    // ~512 plan workgroups of 1024 threads; a (chunk, cell) count must fit 16 bits
+    int64_t want = std::max<int64_t>(1, (512 + N - 1) / N);
+    int64_t chunk = (P + want - 1) / want;
+    chunk = std::min<int64_t>(std::max<int64_t>((chunk + 1023) / 1024 * 1024, 4096), so::P2_CHUNK);
+    L.chunk = (int)chunk;
+    L.chunks = (int)((P + chunk - 1) / chunk);
+    const size_t S = (size_t)N * P;
+    size_t o = 0;
+    L.off_rank = o;       o += align256(S * 4);
+    L.off_coord = o;      o += align256(S * 8);
+    L.off_cell_begin = o; o += align256(((size_t)N * L.bins + 1) * 4);
+    L.off_cnt = o;        o += align256((size_t)N * L.chunks * L.words * 4);
+    L.off_excl = o;       o += align256((size_t)N * L.chunks * L.bins * 4);
+    L.off_totals = o;     o += align256((size_t)N * L.bins * 4);
+    L.off_bsum = o;       o += align256(((size_t)N * L.bins / 1024 + 3) * 4);
+    L.off_G = o;          o += align256(S * (size_t)cpad(C) * 4);
+    L.off_cG = o;         o += align256(S * 8);
+    L.bytes = o;
+    return L;
+}
+so::Plan2 plan2_view(const Plan2Layout &L, void *blob) {
+    char *b = (char *)blob;
+    so::Plan2 p;
+    p.rank = (uint32_t *)(b + L.off_rank);
+    p.coord = (float2 *)(b + L.off_coord);
+    p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
+    p.cnt = (uint32_t *)(b + L.off_cnt);
+    p.excl = (uint32_t *)(b + L.off_excl);
+    p.G = (float *)(b + L.off_G);
+    p.cG = (float2 *)(b + L.off_cG);
+    p.bx = L.bx; p.by = L.by; p.bins = L.bins; p.words = L.words; p.chunks = L.chunks; p.chunk = L.chunk;
+    p.ntx = L.ntx; p.nty = L.nty;
+    return p;
+}
+int build_plan2(const Problem &pb, const float *grid, const float *offset, void *blob) {
+    const Plan2Layout L = plan2_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
+    so::Plan2 pl = plan2_view(L, blob);
+    uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
+    const size_t shm = (size_t)L.words * 4;
+    int rc = allow_lds(so::p2_count, shm);
+    if (rc) return rc;
+    so::p2_count<<<dim3((unsigned)L.chunks, (unsigned)pb.d.N), so::P2_THREADS, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    const int64_t nt = (int64_t)pb.d.N * L.bins;
+    so::p2_totals<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
+    rc = scan_buckets(totals, pl.cell_begin, (uint32_t *)((char *)blob + L.off_bsum), nt, pb.stream);
+    if (rc) return rc;
+    so::p2_excl<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N);
+    so::p2_rank<<<point_grid(pb), kBlock, 0, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    return launch_status();
+}
+
+size_t sorted_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
+                        int have_cI) {
+    const int64_t CP = cpad(C);
+    const size_t T = align256((size_t)N * CP * H * W * 4), S = (size_t)N * P;
+    size_t need = 0;
+    if (!have_cl) need += T;
+    if (stage == CS_STAGE_FORWARD) return need;
+    if (!have_plan) need += plan2_layout(N, C, H, W, P).bytes;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    if (stage == CS_STAGE_BBB_FUSED) need += align256(S * (size_t)CP * 4) + align256(S * 8);   // sorted grad_out_ggout rows + grad_out_ggrid
+    return need;
+}
+
+struct Prepared2 {
+    const float *icl;
+    so::Plan2 plan;
+    bool plan_is_callers;
+};
+int prepare2(const Problem &pb, bool want_plan, const float *input, const float *grid, const float *offset,
+             const float *input_cl, const void *plan, Carve &ws, Prepared2 &out) {
+    const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
+    if (input_cl) {
+        out.icl = input_cl;
+    } else {
+        float *buf = (float *)ws.take((size_t)T * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        if (rc) return rc;
+        out.icl = buf;
+    }
+    out.plan_is_callers = false;
+    if (!want_plan) return CS_OK;
+    const Plan2Layout L = plan2_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
+    if (plan) {
+        out.plan = plan2_view(L, const_cast<void *>(plan));
+        out.plan_is_callers = true;
+    } else {
+        void *blob = ws.take(L.bytes);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = build_plan2(pb, grid, offset, blob);
+        if (rc) return rc;
+        out.plan = plan2_view(L, blob);
+    }
+    return CS_OK;
+}
+
+// gather passes in flight per wave: two landing zones (one at a single channel quad: a pass is the whole wave)
+#define CS_NBUF (CQ >= 2 ? 2 : 1)
+
+template <int MODE>
+int launch_tile_s(const Problem &pb, const so::Plan2 &pl, const float *hOs, const float2 *hGs, const float *offset,
+                  float *grad_input) {
+    const unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntx * pl.nty);
+    int rc = CS_OK;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
+        constexpr size_t shm = so::tile_s_lds<CQ>();
+        rc = allow_lds(so::tile_s<KERNEL, CQ, MODE>, shm);
+        if (!rc) so::tile_s<KERNEL, CQ, MODE><<<nb, 256, shm, pb.stream>>>(pl, hOs, hGs, offset, grad_input, pb.d, pb.f);
+    }));
+    return rc ? rc : launch_status();
+}
+
+int sorted_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
+                    float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
+                    size_t workspace_bytes) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared2 pr;
+    int rc = prepare2(pb, grad_input != nullptr, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    if (!grad_input) {   // nothing to scatter: the point kernel alone
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (so::point_bwd_s<KERNEL, CQ, CS_NBUF, false><<<point_grid(pb), kBlock, so::bwd_lds<CQ, CS_NBUF>(), pb.stream>>>(
+                                          gOut, pr.icl, grid, offset, nullptr, nullptr, grad_grid, pb.d, pb.f))));
+        return launch_status();
+    }
+    rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    if (rc) return rc;
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (so::point_bwd_s<KERNEL, CQ, CS_NBUF, true><<<point_grid(pb), kBlock, so::bwd_lds<CQ, CS_NBUF>(), pb.stream>>>(
+                                      gOut, pr.icl, grid, offset, pr.plan.rank, pr.plan.G, grad_grid, pb.d, pb.f))));
+    rc = launch_status();
+    if (rc) return rc;
+    return launch_tile_s<0>(pb, pr.plan, nullptr, nullptr, offset, grad_input);
+}
+
+int sorted_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
+              const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut, const float *input_cl,
+              const void *plan, void *workspace, size_t workspace_bytes, bool g_valid) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared2 pr;
+    int rc = prepare2(pb, gInput != nullptr, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    const float *cIcl = nullptr;
+    if (cI) {
+        float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        if (rc) return rc;
+        cIcl = buf;
+    }
+    if (gInput) {
+        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+    }
+    const int want_g = (gInput && !(g_valid && pr.plan_is_callers)) ? 1 : 0;
+    const uint32_t *rank = gInput ? pr.plan.rank : nullptr;
+    float *Gs = gInput ? pr.plan.G : nullptr;
+    float2 *cGs = gInput ? pr.plan.cG : nullptr;
+#define CS_SORTED_BB(HAS_CI, SCATTER)                                                                                     \
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {                                                              \
+        constexpr size_t shm = so::bb_lds<CQ, CS_NBUF, HAS_CI>();                                                         \
+        rc = allow_lds(so::point_bb_s<KERNEL, CQ, CS_NBUF, HAS_CI, SCATTER>, shm);                                        \
+        if (!rc) so::point_bb_s<KERNEL, CQ, CS_NBUF, HAS_CI, SCATTER><<<point_grid(pb), kBlock, shm, pb.stream>>>(        \
+                     cIcl, cG, pr.icl, grid, gOut, offset, rank, Gs, cGs, gGrid, ggOut, pb.d, pb.f, want_g);              \
+    }))
+    if (cIcl && gInput) { CS_SORTED_BB(true, true); }
+    else if (cIcl) { CS_SORTED_BB(true, false); }
+    else if (gInput) { CS_SORTED_BB(false, true); }
+    else { CS_SORTED_BB(false, false); }
+#undef CS_SORTED_BB
+    if (rc) return rc;
+    rc = launch_status();
+    if (rc || !gInput) return rc;
+    return launch_tile_s<1>(pb, pr.plan, nullptr, nullptr, offset, gInput);
+}
+
+int sorted_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
+               const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
+               const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_valid,
+               bool cg_valid) {
+    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
+    Prepared2 pr;
+    int rc = prepare2(pb, true, input, grid, offset, input_cl, plan, ws, pr);
+    if (rc) return rc;
+    const int64_t CP = cpad(pb.d.C);
+    float *hOs = (float *)ws.take((size_t)pb.d.S * CP * 4);
+    float2 *hGs = (float2 *)ws.take((size_t)pb.d.S * 8);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    if (rc) return rc;
+    const int want_g = (g_valid && pr.plan_is_callers) ? 0 : 1, want_cg = (cg_valid && pr.plan_is_callers) ? 0 : 1;
+#define CS_SORTED_BBB(TWO)                                                                                               \
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {                                                              \
+        constexpr size_t shm = so::bbb_lds<CQ, CS_NBUF>();                                                                \
+        rc = allow_lds(so::point_bbb_s<KERNEL, CQ, CS_NBUF, TWO>, shm);                                                   \
+        if (!rc) so::point_bbb_s<KERNEL, CQ, CS_NBUF, TWO><<<point_grid(pb), kBlock, shm, pb.stream>>>(                   \
+                     pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank, pr.plan.G, pr.plan.cG, hOs, hGs, ggOut, pb.d,  \
+                     pb.f, want_g, want_cg);                                                                             \
+    }))
+    if (hO) { CS_SORTED_BBB(true); } else { CS_SORTED_BBB(false); }
+#undef CS_SORTED_BBB
+    if (rc) return rc;
+    rc = launch_status();
+    if (rc) return rc;
+    return hO ? launch_tile_s<2>(pb, pr.plan, hOs, hGs, offset, gInput) : launch_tile_s<3>(pb, pr.plan, hOs, hGs, offset, gInput);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,6 +1095,15 @@ void cs_debug_force_path(int mode) { g_force_path.store(mode, std::memory_order_
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
+    if (stage & CS_STAGE_NO_GRAD_INPUT) {
+        // grad_input == NULL: nothing is scattered -- no plan, no rows, no accumulator; what is left is the
+        // channels-last copy of the table (and of grad_out_input, when the second backward carries one)
+        stage &= ~CS_STAGE_NO_GRAD_INPUT;
+        if (stage != CS_STAGE_BACKWARD && stage != CS_STAGE_BACKWARD_BACKWARD) return 0;   // the third backward always scatters
+        const size_t T = cs_pack_bytes(dim, N, C, D, H, W, P);
+        return (have_input_cl ? 0 : T) + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
+    }
+    if (sorted_applies(dim, N, C, H, W, P)) return sorted_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (rows_cl_applies(dim, N, C, P, vol)) {
@@ -893,6 +1133,7 @@ int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
     if (!tiled_applies(2, N, C, H, W, P)) return 0;
+    if (sorted_applies(2, N, C, H, W, P)) return plan2_layout(N, C, H, W, P).bytes;
     return plan_layout(N, H, W, P).bytes;
 }
 
@@ -904,6 +1145,10 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
     if (rc) return rc;
     if (!tiled_applies(2, N, C, H, W, P)) return CS_ERR_UNSUPPORTED;
     if (!grid || !offset || !plan) return CS_ERR_INVALID;
+    if (sorted_applies(2, N, C, H, W, P)) {
+        if (plan_bytes < plan2_layout(N, C, H, W, P).bytes) return CS_ERR_WORKSPACE;
+        return build_plan2(pb, grid, offset, plan);
+    }
     if (plan_bytes < plan_layout(N, H, W, P).bytes) return CS_ERR_WORKSPACE;
     return build_plan(pb, grid, offset, plan);
 }
@@ -933,6 +1178,9 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
+    const bool sorted = tiled && sorted_applies(dim, N, C, H, W, P);                                              \
+    bool g_sorted = false, cg_sorted = false;                                                                     \
+    (void)sorted; (void)g_sorted; (void)cg_sorted;                                                                \
     const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \
     (void)tiled; (void)rows; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;              \
     /* The direct kernels could gather from the channels-last copy too (Dims::tab_ns/tab_cs), but with   \
@@ -946,6 +1194,8 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (layout->grad_output_stride_n < 0 || layout->grad_out_ggout_stride_n < 0) return CS_ERR_INVALID; \
         pb.d.go_ns = layout->grad_output_stride_n;                                                   \
         pb.d.ho_ns = layout->grad_out_ggout_stride_n;                                                \
+        g_sorted = layout->sorted_grad_output_valid != 0;                                            \
+        cg_sorted = layout->sorted_grad_out_grid_valid != 0;                                         \
     }
 
 // zero-element tensors legitimately come with null data pointers
@@ -969,6 +1219,9 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    if (sorted)
+        return sorted_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
+                               workspace_bytes);
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                               workspace_bytes);
@@ -992,8 +1245,12 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     // exact + grad_out_input: the grad_out_input -> grad_grid term is only in the direct kernel (run_bb)
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
-    const bool via_rows = rows || (tiled && pb.f.exact && grad_out_input && log2_exact(C) >= 1 && N <= 65535);
-    if (tiled && !via_rows)
+    const bool exact_ci = tiled && pb.f.exact && grad_out_input;
+    const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
+    if (sorted && !exact_ci)
+        return sorted_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
+                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
+    if (tiled && !exact_ci)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
     if (via_rows) {
@@ -1016,6 +1273,9 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    if (sorted)
+        return sorted_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
+                          grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, cg_sorted);
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
@@ -1039,6 +1299,9 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    if (sorted)
+        return sorted_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
+                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, cg_sorted);
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
@@ -1159,7 +1422,9 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
+    bool g_sorted = false, cg_sorted = false;
     CS_LAYOUT()
+    (void)g_sorted; (void)cg_sorted;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
@@ -1171,7 +1436,9 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
+    bool g_sorted = false, cg_sorted = false;
     CS_LAYOUT()
+    (void)g_sorted; (void)cg_sorted;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }

@@ -375,9 +375,20 @@ __device__ __forceinline__ void dma_issue(const float4 *tab, const uint32_t (&no
         __builtin_amdgcn_global_load_lds(tab + (size_t)(node[a] == NO_NODE ? 0u : node[a]) * CQ + q, dma + a * 256, 16, 0, 0);
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ float4 dma_read(const float *dma, int a, uint32_t node) {
-    const float4 v = *reinterpret_cast<const float4 *>(dma + a * 256 + (threadIdx.x & 63) * 4);
-    return node == NO_NODE ? zero4() : v;
+// The landing zone is read back in inline assembly: for an ordinary LDS load the compiler's wait-count pass puts an
+// `s_waitcnt vmcnt(0)` in front -- it cannot tell which DMA is still in flight into WHICH zone -- and that would drain
+// the next pass's loads too (seen in the ISA: NBUF = 2 ran like NBUF = 1).  The counted waits are dma_wait_keep's.
+__device__ __forceinline__ void dma_read4(const float *zone, const uint32_t (&node)[4], float4 (&v)[4]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f a, b, c, d;
+    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)(zone + (threadIdx.x & 63) * 4);
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr) : "memory");
+    v[0] = node[0] == NO_NODE ? zero4() : make_float4(a.x, a.y, a.z, a.w);
+    v[1] = node[1] == NO_NODE ? zero4() : make_float4(b.x, b.y, b.z, b.w);
+    v[2] = node[2] == NO_NODE ? zero4() : make_float4(c.x, c.y, c.z, c.w);
+    v[3] = node[3] == NO_NODE ? zero4() : make_float4(d.x, d.y, d.z, d.w);
 }
 
 template <int KERNEL, int CQ>
@@ -495,9 +506,10 @@ __global__ __launch_bounds__(256) void point_forward3(const float *__restrict__ 
         const int s = CQ * sl + sub;
         const float wx0 = rec[R_WX0 * 64 + s], wx1 = rec[R_WX1 * 64 + s], wy0 = rec[R_WY0 * 64 + s], wy1 = rec[R_WY1 * 64 + s];
         const float W[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-        float4 r = zero4();
+        float4 v[4], r = zero4();
+        dma_read4(dma + (sub % NBUF) * DMA_FLOATS, node[sub], v);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) r = fma4(W[a], dma_read(dma + (sub % NBUF) * DMA_FLOATS, a, node[sub][a]), r);
+        for (int a = 0; a < 4; ++a) r = fma4(W[a], v[a], r);
         acc[sub] = r;
     }
     const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63) + CQ * sl;   // first of this lane's CQ points

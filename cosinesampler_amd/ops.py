@@ -110,10 +110,21 @@ class StepContext(object):
         self._cl_key = None
         self._plan = None
         self._plan_key = None
+        # which tensors' cell-sorted copies the plan holds (2D sorted path, include/cosine_sampler.h
+        # cs_cotangent_layout.sorted_*_valid): written by the first stage that scatters, read by the later ones
+        self._sorted_go = None
+        self._sorted_cg = None
 
     @staticmethod
     def _key(t):
         return (t.data_ptr(), t._version, tuple(t.shape), t.device)
+
+    @staticmethod
+    def _ckey(t):
+        """identity of a cotangent's bytes: address, version counter, shape, strides (+ the testing knob's epoch)"""
+        if t is None:
+            return ("none", _force_epoch)
+        return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), _force_epoch)
 
     def input_cl(self, lib, input, dim, shape, P, stream):
         key = self._key(input)
@@ -130,11 +141,12 @@ class StepContext(object):
 
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
         key = self._key(grid) + (offset.data_ptr(),) + tuple(shape[2:]) + (int(padding_mode), bool(align_corners),
-                                                                            bool(multicell))
+                                                                            bool(multicell), _force_epoch)
         if self._plan_key != key:
             sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
             nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
             self._plan, self._plan_key = None, key
+            self._sorted_go = self._sorted_cg = None
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
                 _lib.check(getattr(lib, "cs%dd_plan_build" % dim)(
@@ -144,8 +156,12 @@ class StepContext(object):
         return self._plan
 
 
+_force_epoch = 0
+
+
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
-          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None):
+          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
+          grad_out_grid=None, sorts_cg=False):
     if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
@@ -160,22 +176,38 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
             cl = ctx.input_cl(lib, input, dim, shape, P, stream)
             if want_plan:
                 plan = ctx.plan(lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream)
-        need = lib.cs_workspace_bytes(dim, _lib.STAGE_ID[stage], shape[0], shape[1], D, shape[-2], shape[-1], P,
+        stage_id = _lib.STAGE_ID[stage]
+        if stage in ("backward", "backward_backward") and not want_plan:
+            stage_id |= _lib.STAGE_NO_GRAD_INPUT       # grad_input is not wanted: no plan, no scatter scratch
+        need = lib.cs_workspace_bytes(dim, stage_id, shape[0], shape[1], D, shape[-2], shape[-1], P,
                                       int(cl is not None), int(plan is not None), int(have_cI))
         ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
         tail = (_ptr(cl), _ptr(plan), _ptr(ws), need, stream)
         if stage != "forward":
             CP = shape[1] * P
-            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns)
+            go_key = cg_key = None
+            g_valid = cg_valid = 0
+            if plan is not None:
+                go_key, cg_key = ctx._ckey(grad_output), ctx._ckey(grad_out_grid)
+                g_valid, cg_valid = int(ctx._sorted_go == go_key), int(ctx._sorted_cg == cg_key)
+            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
+                                          cg_valid)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
+    if stage != "forward" and plan is not None:   # a stage that was handed a plan scatters: the plan now holds these
+        ctx._sorted_go = go_key
+        if sorts_cg:
+            ctx._sorted_cg = cg_key
 
 
 def force_path(mode):
     """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 fast paths wherever they exist,
-    3 = 2 without the wave-per-cell kernel for crowded tables."""
+    3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 with round 1's fat-row tiled path instead of the
+    cell-sorted one."""
+    global _force_epoch
+    _force_epoch += 1
     _lib.load().cs_debug_force_path(int(mode))
 
 
@@ -203,7 +235,7 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     grad_grid = torch.empty_like(grid)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
                             _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
-          ctx, input, grid, offset, want_plan=bool(input_requires_grad), go_ns=go_ns)
+          ctx, input, grid, offset, want_plan=bool(input_requires_grad), go_ns=go_ns, grad_output=grad_output)
     return grad_input, grad_grid
 
 
@@ -229,7 +261,8 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns)
+          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns, grad_output=grad_output,
+          grad_out_grid=grad_out_grid, sorts_cg=True)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -248,7 +281,7 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns)
+          want_plan=True, go_ns=go_ns, grad_output=grad_output, grad_out_grid=grad_out_grid, sorts_cg=True)
     return grad_input, grad_grad_out
 
 
@@ -272,7 +305,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns, ho_ns=ho_ns)
+          want_plan=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, grad_out_grid=grad_out_grid, sorts_cg=True)
     return grad_input, grad_grad_out
 
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 6
+#define CS_ABI_VERSION 7
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -60,6 +60,10 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
 #define CS_KERNEL_EXACT_MIXED 0x100
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
+/* OR-ed into the stage id: the call will pass grad_input == NULL (first / second backward only) -- nothing is
+ * scattered, so neither a plan nor scatter scratch is needed (every derivative a PINN takes with
+ * autograd.grad(u, x, create_graph=True) is such a call) */
+#define CS_STAGE_NO_GRAD_INPUT 0x10
 
 /* How the channel-major cotangents of a backward stage lie in memory.  The reference demands contiguous
  * (N,C,[Do,]Ho,Wo) tensors (CHECK_CONTIGUOUS, 2d.cpp:5), so PIXEL-style callers, which sum the sampled features
@@ -70,6 +74,14 @@ enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD =
 typedef struct cs_cotangent_layout {
     int64_t grad_output_stride_n;      /* elements between consecutive n of grad_output */
     int64_t grad_out_ggout_stride_n;   /* same for grad_out_ggout (cs*_bbb_fused only) */
+    /* What the caller's `plan` already holds (2D sorted path only; ignored elsewhere and when plan == NULL).  The backward
+     * stages of one training step see the SAME grad_output (modules_2d.py:62, :95 save and re-use it) and the same
+     * grad_out_grid; the first stage that scatters writes their cell-sorted copies into the plan, the later ones only
+     * read them if told that the copy is of THIS tensor -- the library cannot know (contents live in device memory).
+     * Non-zero = "an earlier call with this plan was given this very tensor (same bytes) and wanted grad_input".
+     * Zero is always safe: the stage sorts the tensor again. */
+    int32_t sorted_grad_output_valid;
+    int32_t sorted_grad_out_grid_valid;
 } cs_cotangent_layout;
 
 int cs_abi_version(void);
@@ -106,7 +118,8 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
- * go through the tile walkers, not the wave-per-cell kernel.  Process-wide. */
+ * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 with round 1's fat-row tiled path in place of
+ * the cell-sorted one.  Process-wide. */
 void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */
