@@ -10,7 +10,6 @@
 #include "cs_kernels_direct.cuh"
 #include "cs_points_cl.cuh"
 #include "cs_tiled.cuh"
-#include "cs_sorted.cuh"
 #include "cs_dense3d.cuh"
 
 namespace {
@@ -18,7 +17,6 @@ namespace {
 using cs::Dims;
 using cs::Flags;
 namespace tl = cs::tiled;
-namespace so = cs::sorted;
 
 constexpr int kBlock = 256;
 std::atomic<int> g_force_path{0};  // cs_debug_force_path
@@ -263,7 +261,7 @@ int plan_chunk(int64_t N, int64_t P, int64_t bins) {
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks, chunk, dense;
-    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, bytes;
+    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, off_G, bytes;
 };
 
 // Crowded tables (the reference's own test shapes: 96 tables of 16x16 cells, 10^5 points): the plan bins by cell
@@ -276,7 +274,7 @@ bool dense_applies(int64_t N, int64_t H, int64_t W, int64_t P) {
     return cells <= 12288 && P >= 128 * cells && N * cells < (int64_t)INT32_MAX;
 }
 
-PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
+PlanLayout plan_layout(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     PlanLayout L;
     L.dense = dense_applies(N, H, W, P) ? 1 : 0;
     L.ntx = L.dense ? (int)(W + 1) : (int)((W + 1 + tl::TX - 1) / tl::TX);
@@ -293,6 +291,7 @@ PlanLayout plan_layout(int64_t N, int64_t H, int64_t W, int64_t P) {
     L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.ntiles * 4);
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
     L.off_bsum = o;       o += align256(((size_t)N * L.ntiles / 1024 + 3) * 4);
+    L.off_G = o;          o += L.dense ? 0 : align256((size_t)S * cpad(C) * 4);   // Plan::Gs (walker plans only)
     L.bytes = o;
     return L;
 }
@@ -314,6 +313,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
     p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
+    p.Gs = L.dense ? nullptr : (float *)(b + L.off_G);
     p.ntx = L.ntx;
     p.nty = L.nty;
     p.ntiles = L.ntiles;
@@ -324,7 +324,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
 }
 
 int build_plan(const Problem &pb, const float *grid, const float *offset, void *blob) {
-    PlanLayout L = plan_layout(pb.d.N, pb.d.size[1], pb.d.size[0], pb.d.P);
+    PlanLayout L = plan_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
     tl::Plan pl = plan_view(L, blob);
     uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
     dim3 g((unsigned)L.chunks, (unsigned)pb.d.N);
@@ -366,25 +366,28 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     size_t need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
-    if (!have_plan) need += plan_layout(N, H, W, P).bytes;
+    if (!have_plan) need += plan_layout(N, C, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? tl::row2((int)CP) : tl::row1((int)CP)) * 4);   // fat rows
     return need;
 }
 
-template <bool TWO>
+// SRC / EMIT: see tl::tile_scatter.  Crowded tables (wave per cell) know rows with everything in them only.
+template <int SRC, bool EMIT = false>
 int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *fat, float *grad_input) {
     if (pl.dense) {   // one wave per (n, cell) bucket
+        static_assert(SRC <= 1 || true, "");
+        if (SRC > 1) return CS_ERR_INVALID;
         unsigned nbk = (unsigned)(((int64_t)pb.d.N * pl.ntiles + 3) / 4);
-        CS_DISPATCH_CQT(pb.d.C, (tl::cell_scatter<CQ, TWO><<<nbk, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
+        CS_DISPATCH_CQT(pb.d.C, (tl::cell_scatter<CQ, SRC == 1><<<nbk, 256, 0, pb.stream>>>(fat, pl, grad_input, pb.d)));
         return launch_status();
     }
     unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntiles);
     int rc = CS_OK;
     CS_DISPATCH_CQT(pb.d.C, {
         constexpr size_t shm = tl::tile_scatter_lds<CQ>();
-        rc = allow_lds(tl::tile_scatter<CQ, TWO>, shm);
-        if (!rc) tl::tile_scatter<CQ, TWO><<<nb, 256, shm, pb.stream>>>(fat, pl, grad_input, pb.d);
+        rc = allow_lds(tl::tile_scatter<CQ, SRC, EMIT>, shm);
+        if (!rc) tl::tile_scatter<CQ, SRC, EMIT><<<nb, 256, shm, pb.stream>>>(fat, pl, grad_input, pb.d);
     });
     return rc ? rc : launch_status();
 }
@@ -392,6 +395,7 @@ int launch_tile_scatter(const Problem &pb, const tl::Plan &pl, const float *fat,
 struct Prepared {
     const float *icl;
     tl::Plan plan;
+    bool plan_is_callers;   // it outlives this call: worth leaving the sorted gOut copy in it
 };
 
 // resolve input_cl / plan: use the caller's, or build into the workspace
@@ -407,10 +411,12 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
         if (rc) return rc;
         out.icl = buf;
     }
+    out.plan_is_callers = false;
     if (stage == CS_STAGE_FORWARD) return CS_OK;
-    PlanLayout L = plan_layout(pb.d.N, pb.d.size[1], pb.d.size[0], pb.d.P);
+    PlanLayout L = plan_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
     if (plan) {
         out.plan = plan_view(L, const_cast<void *>(plan));
+        out.plan_is_callers = g_force_path.load(std::memory_order_relaxed) != 4;   // 4: testing, no payload re-use
     } else {
         void *blob = ws.take(L.bytes);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
@@ -468,12 +474,14 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
                                       gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, fat, grad_input);
+    // a caller's plan outlives this call: leave the sorted copy of grad_output in it for the later stages' walkers
+    if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, grad_input);
+    return launch_tile_scatter<0>(pb, pr.plan, fat, grad_input);
 }
 
 int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
              const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut,
-             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
+             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
@@ -487,47 +495,55 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         if (rc) return rc;
         cIcl = buf;
     }
+    // the plan already holds THIS grad_output in sorted order (an earlier stage of the step left it): the point kernel
+    // writes the 16-byte D record only and the walkers stream the payload
+    const bool lean = gInput && g_sorted && pr.plan_is_callers && !pr.plan.dense;
     float *fat = nullptr;
     if (gInput) {
-        fat = (float *)ws.take((size_t)pb.d.S * tl::row1((int)cpad(pb.d.C)) * 4);
+        fat = (float *)ws.take((size_t)pb.d.S * (lean ? 4 : tl::row1((int)cpad(pb.d.C))) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
     }
     const size_t shm = q_lds(tl::row1((int)cpad(pb.d.C)), 12);
-    if (!gInput) {
-        if (cIcl) {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, true, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                              cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
-        } else {
-            CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, false, false><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                              cIcl, cG, pr.icl, grid, gOut, offset, nullptr, gGrid, ggOut, pb.d, pb.f))));
-        }
-        return launch_status();
-    }
-    if (cIcl) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                          cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
-    } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, false, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                                          cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))));
-    }
+#define CS_TILED_BB(HAS_CI, ROWS)                                                                                      \
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, HAS_CI, ROWS><<<point_grid(pb), kBlock, shm, pb.stream>>>( \
+                                      cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))))
+    if (!gInput) { if (cIcl) { CS_TILED_BB(true, 0); } else { CS_TILED_BB(false, 0); } }
+    else if (lean) { if (cIcl) { CS_TILED_BB(true, 2); } else { CS_TILED_BB(false, 2); } }
+    else { if (cIcl) { CS_TILED_BB(true, 1); } else { CS_TILED_BB(false, 1); } }
+#undef CS_TILED_BB
     rc = launch_status();
-    if (rc) return rc;
-    return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
+    if (rc || !gInput) return rc;
+    if (lean) return launch_tile_scatter<2>(pb, pr.plan, fat, gInput);
+    if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
+    return launch_tile_scatter<0>(pb, pr.plan, fat, gInput);
 }
 
 int tiled_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
               const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
-              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
+              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
-    float *fat = (float *)ws.take((size_t)pb.d.S * tl::row2((int)cpad(pb.d.C)) * 4);
+    const bool lean = hO && g_sorted && pr.plan_is_callers && !pr.plan.dense;   // see tiled_bb
+    float *fat = (float *)ws.take((size_t)pb.d.S * (lean ? tl::row3((int)cpad(pb.d.C)) : tl::row2((int)cpad(pb.d.C))) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
+    if (lean) {
+        const size_t shm = q_lds(tl::row3((int)cpad(pb.d.C)), 0);
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
+            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, true>, shm);
+            if (!rc) tl::point_bbb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                         pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f);
+        }));
+        if (rc) return rc;
+        rc = launch_status();
+        if (rc) return rc;
+        return launch_tile_scatter<3>(pb, pr.plan, fat, gInput);
+    }
     if (hO) {
         const size_t shm = q_lds(tl::row2((int)cpad(pb.d.C)), 0);   // 80 KiB at 32 channels
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
@@ -538,243 +554,16 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         if (rc) return rc;
         rc = launch_status();
         if (rc) return rc;
-        return launch_tile_scatter<true>(pb, pr.plan, fat, gInput);
+        if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<1, true>(pb, pr.plan, fat, gInput);
+        return launch_tile_scatter<1>(pb, pr.plan, fat, gInput);
     } else {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
-        return launch_tile_scatter<false>(pb, pr.plan, fat, gInput);
+        if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
+        return launch_tile_scatter<0>(pb, pr.plan, fat, gInput);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// sorted path (cs_sorted.cuh): the tiled problems whose cell histogram fits the LDS as 16-bit counters and whose
-// tables are not crowded.  Same prepared objects as the tiled path; the plan blob has its own layout.
-// ------------------------------------------------------------------------------------------------
-bool sorted_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
-    if (g_force_path.load(std::memory_order_relaxed) == 4) return false;   // testing: round 1's fat-row path
-    if (!tiled_applies(dim, N, C, H, W, P) || dense_applies(N, H, W, P)) return false;
-    const int64_t bins = (W + 1) * (H + 1);
-    return bins <= so::P2_MAX_BINS && N * bins < (int64_t)INT32_MAX;
-}
-
-struct Plan2Layout {
-    int bx, by, bins, words, chunks, chunk, ntx, nty;
-    size_t off_rank, off_coord, off_cell_begin, off_cnt, off_excl, off_totals, off_bsum, off_G, off_cG, bytes;
-};
-Plan2Layout plan2_layout(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
-    Plan2Layout L;
-    L.bx = (int)(W + 1);
-    L.by = (int)(H + 1);
-    L.bins = L.bx * L.by;
-    L.words = (L.bins + 1) / 2;
-    L.ntx = (L.bx + tl::TX - 1) / tl::TX;
-    L.nty = (L.by + tl::TY - 1) / tl::TY;
-    // ~512 plan workgroups of 1024 threads; a (chunk, cell) count must fit 16 bits
-    int64_t want = std::max<int64_t>(1, (512 + N - 1) / N);
-    int64_t chunk = (P + want - 1) / want;
-    chunk = std::min<int64_t>(std::max<int64_t>((chunk + 1023) / 1024 * 1024, 4096), so::P2_CHUNK);
-    L.chunk = (int)chunk;
-    L.chunks = (int)((P + chunk - 1) / chunk);
-    const size_t S = (size_t)N * P;
-    size_t o = 0;
-    L.off_rank = o;       o += align256(S * 4);
-    L.off_coord = o;      o += align256(S * 8);
-    L.off_cell_begin = o; o += align256(((size_t)N * L.bins + 1) * 4);
-    L.off_cnt = o;        o += align256((size_t)N * L.chunks * L.words * 4);
-    L.off_excl = o;       o += align256((size_t)N * L.chunks * L.bins * 4);
-    L.off_totals = o;     o += align256((size_t)N * L.bins * 4);
-    L.off_bsum = o;       o += align256(((size_t)N * L.bins / 1024 + 3) * 4);
-    L.off_G = o;          o += align256(S * (size_t)cpad(C) * 4);
-    L.off_cG = o;         o += align256(S * 8);
-    L.bytes = o;
-    return L;
-}
-so::Plan2 plan2_view(const Plan2Layout &L, void *blob) {
-    char *b = (char *)blob;
-    so::Plan2 p;
-    p.rank = (uint32_t *)(b + L.off_rank);
-    p.coord = (float2 *)(b + L.off_coord);
-    p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
-    p.cnt = (uint32_t *)(b + L.off_cnt);
-    p.excl = (uint32_t *)(b + L.off_excl);
-    p.G = (float *)(b + L.off_G);
-    p.cG = (float2 *)(b + L.off_cG);
-    p.bx = L.bx; p.by = L.by; p.bins = L.bins; p.words = L.words; p.chunks = L.chunks; p.chunk = L.chunk;
-    p.ntx = L.ntx; p.nty = L.nty;
-    return p;
-}
-int build_plan2(const Problem &pb, const float *grid, const float *offset, void *blob) {
-    const Plan2Layout L = plan2_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
-    so::Plan2 pl = plan2_view(L, blob);
-    uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
-    const size_t shm = (size_t)L.words * 4;
-    int rc = allow_lds(so::p2_count, shm);
-    if (rc) return rc;
-    so::p2_count<<<dim3((unsigned)L.chunks, (unsigned)pb.d.N), so::P2_THREADS, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
-    const int64_t nt = (int64_t)pb.d.N * L.bins;
-    so::p2_totals<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
-    rc = scan_buckets(totals, pl.cell_begin, (uint32_t *)((char *)blob + L.off_bsum), nt, pb.stream);
-    if (rc) return rc;
-    so::p2_excl<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N);
-    so::p2_rank<<<point_grid(pb), kBlock, 0, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
-    return launch_status();
-}
-
-size_t sorted_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
-                        int have_cI) {
-    const int64_t CP = cpad(C);
-    const size_t T = align256((size_t)N * CP * H * W * 4), S = (size_t)N * P;
-    size_t need = 0;
-    if (!have_cl) need += T;
-    if (stage == CS_STAGE_FORWARD) return need;
-    if (!have_plan) need += plan2_layout(N, C, H, W, P).bytes;
-    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
-    if (stage == CS_STAGE_BBB_FUSED) need += align256(S * (size_t)CP * 4) + align256(S * 8);   // sorted grad_out_ggout rows + grad_out_ggrid
-    return need;
-}
-
-struct Prepared2 {
-    const float *icl;
-    so::Plan2 plan;
-    bool plan_is_callers;
-};
-int prepare2(const Problem &pb, bool want_plan, const float *input, const float *grid, const float *offset,
-             const float *input_cl, const void *plan, Carve &ws, Prepared2 &out) {
-    const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
-    if (input_cl) {
-        out.icl = input_cl;
-    } else {
-        float *buf = (float *)ws.take((size_t)T * 4);
-        if (!ws.ok()) return CS_ERR_WORKSPACE;
-        int rc = pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
-        if (rc) return rc;
-        out.icl = buf;
-    }
-    out.plan_is_callers = false;
-    if (!want_plan) return CS_OK;
-    const Plan2Layout L = plan2_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
-    if (plan) {
-        out.plan = plan2_view(L, const_cast<void *>(plan));
-        out.plan_is_callers = true;
-    } else {
-        void *blob = ws.take(L.bytes);
-        if (!ws.ok()) return CS_ERR_WORKSPACE;
-        int rc = build_plan2(pb, grid, offset, blob);
-        if (rc) return rc;
-        out.plan = plan2_view(L, blob);
-    }
-    return CS_OK;
-}
-
-// gather passes in flight per wave: two landing zones (one at a single channel quad: a pass is the whole wave)
-#define CS_NBUF (CQ >= 2 ? 2 : 1)
-
-template <int MODE>
-int launch_tile_s(const Problem &pb, const so::Plan2 &pl, const float *hOs, const float2 *hGs, const float *offset,
-                  float *grad_input) {
-    const unsigned nb = (unsigned)((int64_t)pb.d.N * pl.ntx * pl.nty);
-    int rc = CS_OK;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
-        constexpr size_t shm = so::tile_s_lds<CQ>();
-        rc = allow_lds(so::tile_s<KERNEL, CQ, MODE>, shm);
-        if (!rc) so::tile_s<KERNEL, CQ, MODE><<<nb, 256, shm, pb.stream>>>(pl, hOs, hGs, offset, grad_input, pb.d, pb.f);
-    }));
-    return rc ? rc : launch_status();
-}
-
-int sorted_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
-                    float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
-                    size_t workspace_bytes) {
-    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
-    Prepared2 pr;
-    int rc = prepare2(pb, grad_input != nullptr, input, grid, offset, input_cl, plan, ws, pr);
-    if (rc) return rc;
-    if (!grad_input) {   // nothing to scatter: the point kernel alone
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (so::point_bwd_s<KERNEL, CQ, CS_NBUF, false><<<point_grid(pb), kBlock, so::bwd_lds<CQ, CS_NBUF>(), pb.stream>>>(
-                                          gOut, pr.icl, grid, offset, nullptr, nullptr, grad_grid, pb.d, pb.f))));
-        return launch_status();
-    }
-    rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
-    if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (so::point_bwd_s<KERNEL, CQ, CS_NBUF, true><<<point_grid(pb), kBlock, so::bwd_lds<CQ, CS_NBUF>(), pb.stream>>>(
-                                      gOut, pr.icl, grid, offset, pr.plan.rank, pr.plan.G, grad_grid, pb.d, pb.f))));
-    rc = launch_status();
-    if (rc) return rc;
-    return launch_tile_s<0>(pb, pr.plan, nullptr, nullptr, offset, grad_input);
-}
-
-int sorted_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
-              const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut, const float *input_cl,
-              const void *plan, void *workspace, size_t workspace_bytes, bool g_valid) {
-    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
-    Prepared2 pr;
-    int rc = prepare2(pb, gInput != nullptr, input, grid, offset, input_cl, plan, ws, pr);
-    if (rc) return rc;
-    const float *cIcl = nullptr;
-    if (cI) {
-        float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
-        if (!ws.ok()) return CS_ERR_WORKSPACE;
-        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
-        if (rc) return rc;
-        cIcl = buf;
-    }
-    if (gInput) {
-        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
-        if (rc) return rc;
-    }
-    const int want_g = (gInput && !(g_valid && pr.plan_is_callers)) ? 1 : 0;
-    const uint32_t *rank = gInput ? pr.plan.rank : nullptr;
-    float *Gs = gInput ? pr.plan.G : nullptr;
-    float2 *cGs = gInput ? pr.plan.cG : nullptr;
-#define CS_SORTED_BB(HAS_CI, SCATTER)                                                                                     \
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {                                                              \
-        constexpr size_t shm = so::bb_lds<CQ, CS_NBUF, HAS_CI>();                                                         \
-        rc = allow_lds(so::point_bb_s<KERNEL, CQ, CS_NBUF, HAS_CI, SCATTER>, shm);                                        \
-        if (!rc) so::point_bb_s<KERNEL, CQ, CS_NBUF, HAS_CI, SCATTER><<<point_grid(pb), kBlock, shm, pb.stream>>>(        \
-                     cIcl, cG, pr.icl, grid, gOut, offset, rank, Gs, cGs, gGrid, ggOut, pb.d, pb.f, want_g);              \
-    }))
-    if (cIcl && gInput) { CS_SORTED_BB(true, true); }
-    else if (cIcl) { CS_SORTED_BB(true, false); }
-    else if (gInput) { CS_SORTED_BB(false, true); }
-    else { CS_SORTED_BB(false, false); }
-#undef CS_SORTED_BB
-    if (rc) return rc;
-    rc = launch_status();
-    if (rc || !gInput) return rc;
-    return launch_tile_s<1>(pb, pr.plan, nullptr, nullptr, offset, gInput);
-}
-
-int sorted_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
-               const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
-               const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_valid,
-               bool cg_valid) {
-    Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
-    Prepared2 pr;
-    int rc = prepare2(pb, true, input, grid, offset, input_cl, plan, ws, pr);
-    if (rc) return rc;
-    const int64_t CP = cpad(pb.d.C);
-    float *hOs = (float *)ws.take((size_t)pb.d.S * CP * 4);
-    float2 *hGs = (float2 *)ws.take((size_t)pb.d.S * 8);
-    if (!ws.ok()) return CS_ERR_WORKSPACE;
-    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
-    if (rc) return rc;
-    const int want_g = (g_valid && pr.plan_is_callers) ? 0 : 1, want_cg = (cg_valid && pr.plan_is_callers) ? 0 : 1;
-#define CS_SORTED_BBB(TWO)                                                                                               \
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {                                                              \
-        constexpr size_t shm = so::bbb_lds<CQ, CS_NBUF>();                                                                \
-        rc = allow_lds(so::point_bbb_s<KERNEL, CQ, CS_NBUF, TWO>, shm);                                                   \
-        if (!rc) so::point_bbb_s<KERNEL, CQ, CS_NBUF, TWO><<<point_grid(pb), kBlock, shm, pb.stream>>>(                   \
-                     pr.icl, grid, gOut, cG, hG, hO, offset, pr.plan.rank, pr.plan.G, pr.plan.cG, hOs, hGs, ggOut, pb.d,  \
-                     pb.f, want_g, want_cg);                                                                             \
-    }))
-    if (hO) { CS_SORTED_BBB(true); } else { CS_SORTED_BBB(false); }
-#undef CS_SORTED_BBB
-    if (rc) return rc;
-    rc = launch_status();
-    if (rc) return rc;
-    return hO ? launch_tile_s<2>(pb, pr.plan, hOs, hGs, offset, gInput) : launch_tile_s<3>(pb, pr.plan, hOs, hGs, offset, gInput);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -824,6 +613,7 @@ tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
     tl::Plan p;
     p.sorted = (uint32_t *)(b + L.off_sorted);
     p.key = nullptr;
+    p.Gs = nullptr;
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
     p.cell_begin = nullptr;
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
@@ -1103,7 +893,6 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
         const size_t T = cs_pack_bytes(dim, N, C, D, H, W, P);
         return (have_input_cl ? 0 : T) + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
     }
-    if (sorted_applies(dim, N, C, H, W, P)) return sorted_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (rows_cl_applies(dim, N, C, P, vol)) {
@@ -1133,8 +922,7 @@ int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
     if (!tiled_applies(2, N, C, H, W, P)) return 0;
-    if (sorted_applies(2, N, C, H, W, P)) return plan2_layout(N, C, H, W, P).bytes;
-    return plan_layout(N, H, W, P).bytes;
+    return plan_layout(N, C, H, W, P).bytes;
 }
 
 int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
@@ -1145,11 +933,7 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
     if (rc) return rc;
     if (!tiled_applies(2, N, C, H, W, P)) return CS_ERR_UNSUPPORTED;
     if (!grid || !offset || !plan) return CS_ERR_INVALID;
-    if (sorted_applies(2, N, C, H, W, P)) {
-        if (plan_bytes < plan2_layout(N, C, H, W, P).bytes) return CS_ERR_WORKSPACE;
-        return build_plan2(pb, grid, offset, plan);
-    }
-    if (plan_bytes < plan_layout(N, H, W, P).bytes) return CS_ERR_WORKSPACE;
+    if (plan_bytes < plan_layout(N, C, H, W, P).bytes) return CS_ERR_WORKSPACE;
     return build_plan(pb, grid, offset, plan);
 }
 
@@ -1178,9 +962,8 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
-    const bool sorted = tiled && sorted_applies(dim, N, C, H, W, P);                                              \
-    bool g_sorted = false, cg_sorted = false;                                                                     \
-    (void)sorted; (void)g_sorted; (void)cg_sorted;                                                                \
+    bool g_sorted = false;                                                                                        \
+    (void)g_sorted;                                                                                               \
     const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \
     (void)tiled; (void)rows; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;              \
     /* The direct kernels could gather from the channels-last copy too (Dims::tab_ns/tab_cs), but with   \
@@ -1195,7 +978,6 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         pb.d.go_ns = layout->grad_output_stride_n;                                                   \
         pb.d.ho_ns = layout->grad_out_ggout_stride_n;                                                \
         g_sorted = layout->sorted_grad_output_valid != 0;                                            \
-        cg_sorted = layout->sorted_grad_out_grid_valid != 0;                                         \
     }
 
 // zero-element tensors legitimately come with null data pointers
@@ -1219,9 +1001,6 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
-    if (sorted)
-        return sorted_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
-                               workspace_bytes);
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                               workspace_bytes);
@@ -1247,12 +1026,9 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
     const bool exact_ci = tiled && pb.f.exact && grad_out_input;
     const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
-    if (sorted && !exact_ci)
-        return sorted_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
-                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
     if (tiled && !exact_ci)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
-                        grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+                        grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
     if (via_rows) {
         int rc = run_bb<2>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
@@ -1273,12 +1049,9 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
-    if (sorted)
-        return sorted_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
-                          grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, cg_sorted);
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
-                         grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -1299,12 +1072,9 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
-    if (sorted)
-        return sorted_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
-                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, cg_sorted);
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
-                         grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+                         grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);
@@ -1422,9 +1192,9 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
-    bool g_sorted = false, cg_sorted = false;
+    bool g_sorted = false;
     CS_LAYOUT()
-    (void)g_sorted; (void)cg_sorted;
+    (void)g_sorted;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
@@ -1436,9 +1206,9 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
-    bool g_sorted = false, cg_sorted = false;
+    bool g_sorted = false;
     CS_LAYOUT()
-    (void)g_sorted; (void)cg_sorted;
+    (void)g_sorted;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }

@@ -59,6 +59,8 @@ struct Plan {
     int chunk;             // samples per plan workgroup (CHUNK; larger when the histogram is large)
     int dense;             // crowded tables: the bins ARE the cells -- ntx = W+1, ntiles = (W+1)(H+1), `sorted` is written
                            // by plan_scatter directly, no per-tile pass, no cell_begin; consumed by cell_scatter
+    float *Gs;             // [S*CP] (walker plans only) grad_output rows in SORTED order, channels-last: left by the
+                           // first tile kernel that fetched them by sample id, streamed by the later stages' walkers
 };
 
 struct Geo2 {  // tile coordinates of a sample; u = lo + 1 so that lo = -1 (only the high node valid) is cell 0
@@ -724,7 +726,9 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
 
 // second backward.  LDS stage row: g | Dm[4] (the fat row) and, in `rec`, node ids; the per sample coefficient
 // sets Sx, Sy (and W for HAS_CI) live in a second record block `co`: [12][64]
-template <int KERNEL, int CQ, bool HAS_CI, bool WANT_ROWS>
+// ROWS: 0 nothing for the scatter (grad_input not wanted), 1 the fat rows [gOut | D], 2 the 16-byte D record alone
+// (p-ordered, `fat` = S float4): the walkers then take gOut from the sorted copy an earlier stage left (Plan::Gs)
+template <int KERNEL, int CQ, bool HAS_CI, int ROWS>
 __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                   const float *__restrict__ icl, const float *__restrict__ grid,
                                                   const float *__restrict__ gOut, const float *__restrict__ offset,
@@ -759,6 +763,11 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
             if (HAS_CI) co[(8 + a) * 64 + lane] = sm.W[a];
         }
         *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
+        if (ROWS == 2 && sm.live) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = {Dm[0], Dm[1], Dm[2], Dm[3]};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(fat + sm.s * 4));
+        }
         q_put_nodes(rec, sm);
     }
     __syncthreads();
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
-    if (WANT_ROWS) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
+    if (ROWS == 1) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
         const int sl = sub * (64 / CQ) + lane / CQ;
@@ -802,14 +811,18 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     if (sm.live) *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(rec[4 * 64 + lane], rec[5 * 64 + lane]);
 }
 
-// fused third backward.  Stage row = the fat row: TWO ? [gOut | hO | E | D] : [gOut | E]
-template <int KERNEL, int CQ, bool TWO>
+// fused third backward.  Stage row = the fat row: TWO ? [gOut | hO | E | D] : [gOut | E];
+// LEAN (with TWO): [hO | E | D] -- grad_output is neither read nor written again, the walkers stream its sorted copy
+// (padding these rows to whole 128-byte lines was measured and dropped: point kernel +0.09 ms, walkers -0.02 ms)
+__host__ __device__ constexpr int row3(int C) { return C + 8; }
+template <int KERNEL, int CQ, bool TWO, bool LEAN = false>
 __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, const float *__restrict__ grid,
                                                    const float *__restrict__ gOut, const float *__restrict__ cG,
                                                    const float *__restrict__ hG, const float *__restrict__ hO,
                                                    const float *__restrict__ offset, float *__restrict__ fat,
                                                    float *__restrict__ ggOut, Dims d, Flags f) {
-    constexpr int C = 4 * CQ, STRIDE = TWO ? row2(C) : row1(C), EOFF = TWO ? 2 * C : C;
+    static_assert(!LEAN || TWO, "the lean rows carry grad_out_ggout");
+    constexpr int C = 4 * CQ, STRIDE = LEAN ? row3(C) : TWO ? row2(C) : row1(C), EOFF = LEAN ? C : TWO ? 2 * C : C;
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC);
     float *rec = stage + 64 * STRIDE;
@@ -827,14 +840,16 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
             if (f.exact) Em[a] = fmaf(sm.mixed2(a), hg.x * cg.y + hg.y * cg.x, Em[a]);
         }
         float *row = stage + lane * STRIDE;
-        float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
-        put_payload<CQ>(row, g);
+        if (!LEAN) {
+            float4 g[CQ];
+            load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
+            put_payload<CQ>(row, g);
+        }
         if (TWO) {
             float4 h[CQ];
             load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h, d.C);
-            put_payload<CQ>(row + C, h);
-            *reinterpret_cast<float4 *>(row + 2 * C + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
+            put_payload<CQ>(row + (LEAN ? 0 : C), h);
+            *reinterpret_cast<float4 *>(row + EOFF + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
         }
         *reinterpret_cast<float4 *>(row + EOFF) = make_float4(Em[0], Em[1], Em[2], Em[3]);
         q_put_nodes(rec, sm);
@@ -874,11 +889,19 @@ template <int CQ>
 constexpr size_t tile_scatter_lds() {   // top + bot images + the cell table
     return (size_t)2 * TY * (TX / CQ) * (CQ + 1) * CQ * 16 + (CELLS + 1 + 3) / 4 * 16;
 }
-template <int CQ, bool TWO>
+// SRC says where a sample's payload(s) and coefficients come from:
+//   0  fat rows [gOut | k]                 fetched by sample id          (first / second backward)
+//   1  fat rows [gOut | hO | E | D]        fetched by sample id          (fused third backward)
+//   2  gOut streamed from Plan::Gs (sorted), the 16-byte record k fetched by id          (second backward)
+//   3  gOut streamed from Plan::Gs, rows [hO | E | D] fetched by id                      (fused third backward)
+// EMIT (SRC 0, 1): the gOut quads also leave in sorted order to Plan::Gs -- sequential 64-byte rows, each walker its run
+template <int CQ, int SRC, bool EMIT = false>
 __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fat, Plan pl,
                                                     float *__restrict__ grad_input, Dims d) {
     constexpr int C = 4 * CQ;
-    constexpr int STRIDE = TWO ? row2(C) : row1(C);
+    constexpr bool TWO = SRC == 1 || SRC == 3;
+    constexpr int STRIDE = SRC == 0 ? row1(C) : SRC == 1 ? row2(C) : SRC == 2 ? 4 : row3(C);
+    static_assert(!EMIT || SRC <= 1, "only the rows that carry gOut can emit it");
     constexpr int SEGW = CQ;                   // cells per walker
     constexpr int NSEG = TX / SEGW;            // walkers per cell row
     constexpr int NODES = NSEG * (SEGW + 1);   // node slots per cell row (run ends are duplicated)
@@ -913,6 +936,7 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
         const uint32_t j1 = cbr[SEGW];
         uint32_t nb = cbr[1];                   // first position of the next cell
         const uint32_t *sorted = pl.sorted + b0;
+        float *gs = pl.Gs + (int64_t)b0 * C + 4 * q;     // this bucket's rows of the sorted gOut copy, this lane's quad
         const uint32_t jbeg = cbr[0];
         uint32_t ids[U];                        // sample ids of the NEXT batch: fetched one batch ahead so that
 #pragma unroll                                  // the row fetches never wait on the id fetch
@@ -922,14 +946,29 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
 #pragma unroll
             for (int u = 0; u < U; ++u) {       // all row loads of the batch first
                 const float *row = fat + (int64_t)ids[u] * STRIDE;
-                g[u] = ld_row(row + 4 * q);
-                if (TWO) {
+                if (SRC == 0) {
+                    g[u] = ld_row(row + 4 * q);
+                    k[u] = ld_row(row + C);
+                } else if (SRC == 1) {
+                    g[u] = ld_row(row + 4 * q);
                     h[u] = ld_row(row + C + 4 * q);
                     k[u] = ld_row(row + 2 * C);
                     k2[u] = ld_row(row + 2 * C + 4);
                 } else {
-                    k[u] = ld_row(row + C);
+                    g[u] = ld_row(gs + (int64_t)min(j + u, j1 - 1) * C);
+                    if (SRC == 2) {
+                        k[u] = ld_row(row);
+                    } else {
+                        h[u] = ld_row(row + 4 * q);
+                        k[u] = ld_row(row + C);
+                        k2[u] = ld_row(row + C + 4);
+                    }
                 }
+            }
+            if (EMIT) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (j + u < j1) *reinterpret_cast<float4 *>(gs + (int64_t)(j + u) * C) = g[u];
             }
             if (j + U < j1) {
 #pragma unroll

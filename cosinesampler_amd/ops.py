@@ -110,10 +110,9 @@ class StepContext(object):
         self._cl_key = None
         self._plan = None
         self._plan_key = None
-        # which tensors' cell-sorted copies the plan holds (2D sorted path, include/cosine_sampler.h
-        # cs_cotangent_layout.sorted_*_valid): written by the first stage that scatters, read by the later ones
+        # whose cell-sorted copy the plan holds (include/cosine_sampler.h, cs_cotangent_layout.sorted_grad_output_valid):
+        # left there by the first stage that scatters, streamed by the later ones
         self._sorted_go = None
-        self._sorted_cg = None
 
     @staticmethod
     def _key(t):
@@ -146,7 +145,7 @@ class StepContext(object):
             sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
             nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
             self._plan, self._plan_key = None, key
-            self._sorted_go = self._sorted_cg = None
+            self._sorted_go = None
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
                 _lib.check(getattr(lib, "cs%dd_plan_build" % dim)(
@@ -160,8 +159,7 @@ _force_epoch = 0
 
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
-          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
-          grad_out_grid=None, sorts_cg=False):
+          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None):
     if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
@@ -185,27 +183,23 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
         tail = (_ptr(cl), _ptr(plan), _ptr(ws), need, stream)
         if stage != "forward":
             CP = shape[1] * P
-            go_key = cg_key = None
-            g_valid = cg_valid = 0
+            go_key, g_valid = None, 0
             if plan is not None:
-                go_key, cg_key = ctx._ckey(grad_output), ctx._ckey(grad_out_grid)
-                g_valid, cg_valid = int(ctx._sorted_go == go_key), int(ctx._sorted_cg == cg_key)
-            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
-                                          cg_valid)
+                go_key = ctx._ckey(grad_output)
+                g_valid = int(ctx._sorted_go == go_key)
+            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid, 0)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
-    if stage != "forward" and plan is not None:   # a stage that was handed a plan scatters: the plan now holds these
+    if stage != "forward" and plan is not None:   # a stage that was handed a plan scatters: the plan now holds this one
         ctx._sorted_go = go_key
-        if sorts_cg:
-            ctx._sorted_cg = cg_key
 
 
 def force_path(mode):
     """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 fast paths wherever they exist,
-    3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 with round 1's fat-row tiled path instead of the
-    cell-sorted one."""
+    3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 without the re-use of the sorted grad_output copy
+    between the stages of a step."""
     global _force_epoch
     _force_epoch += 1
     _lib.load().cs_debug_force_path(int(mode))
@@ -261,8 +255,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns, grad_output=grad_output,
-          grad_out_grid=grad_out_grid, sorts_cg=True)
+          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns, grad_output=grad_output)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -281,7 +274,7 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns, grad_output=grad_output, grad_out_grid=grad_out_grid, sorts_cg=True)
+          want_plan=True, go_ns=go_ns, grad_output=grad_output)
     return grad_input, grad_grad_out
 
 
@@ -305,7 +298,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, grad_out_grid=grad_out_grid, sorts_cg=True)
+          want_plan=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output)
     return grad_input, grad_grad_out
 
 

@@ -74,14 +74,14 @@ enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD =
 typedef struct cs_cotangent_layout {
     int64_t grad_output_stride_n;      /* elements between consecutive n of grad_output */
     int64_t grad_out_ggout_stride_n;   /* same for grad_out_ggout (cs*_bbb_fused only) */
-    /* What the caller's `plan` already holds (2D sorted path only; ignored elsewhere and when plan == NULL).  The backward
-     * stages of one training step see the SAME grad_output (modules_2d.py:62, :95 save and re-use it) and the same
-     * grad_out_grid; the first stage that scatters writes their cell-sorted copies into the plan, the later ones only
-     * read them if told that the copy is of THIS tensor -- the library cannot know (contents live in device memory).
-     * Non-zero = "an earlier call with this plan was given this very tensor (same bytes) and wanted grad_input".
-     * Zero is always safe: the stage sorts the tensor again. */
+    /* Non-zero: the caller's `plan` already holds the cell-sorted copy of THIS grad_output (2D walker plans only;
+     * ignored elsewhere and when plan == NULL).  The backward stages of one training step are handed the same
+     * grad_output (modules_2d.py:62, :95 save and re-use it); the first stage that scatters with a caller's plan leaves
+     * its rows in the plan in sorted order, and a later stage that is told so streams them instead of writing and
+     * fetching them again.  The library cannot check (the bytes live in device memory): set it only if an earlier
+     * call with this plan was given this very tensor, unchanged, and a non-NULL grad_input.  Zero is always safe. */
     int32_t sorted_grad_output_valid;
-    int32_t sorted_grad_out_grid_valid;
+    int32_t reserved;
 } cs_cotangent_layout;
 
 int cs_abi_version(void);
@@ -118,8 +118,8 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
- * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 with round 1's fat-row tiled path in place of
- * the cell-sorted one.  Process-wide. */
+ * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 without the re-use of the sorted grad_output
+ * copy between the stages of a step.  Process-wide. */
 void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */

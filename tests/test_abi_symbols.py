@@ -40,14 +40,13 @@ def test_loader_binds_and_reports_errors_without_gpu():
     # headline config: the tiled path wants scratch for the channels-last copy (64 MiB) in forward ...
     assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 16 * 256 * 256 * 4
     assert lib.cs_workspace_bytes(2, 0, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
-    # ... nothing but the plan in the first two backward stages (sorted path: the plan holds the sorted payload), the
-    # sorted rows of grad_out_ggout (64 B) and of grad_out_ggrid (8 B) per sample in the fused third backward
+    # ... one fat row (C payload floats + 4 coefficients) per sample in backward (plus the plan unless one is passed in);
+    # the plan has room for the sorted copy of one grad_output (64 B per sample) next to the ids
     S = 16 << 20
     plan = lib.cs2d_plan_bytes(16, 16, 256, 256, 1 << 20)
-    assert plan > S * (4 + 8 + 64 + 8)          # rank, sorted coordinates, sorted grad_output rows, sorted grad_out_grid
-    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == 0
-    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == plan
-    assert lib.cs_workspace_bytes(2, 3, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 72
+    assert plan > S * (4 + 4 + 64)
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 1, 0) == S * 80
+    assert lib.cs_workspace_bytes(2, 1, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == S * 80 + plan
     # a backward call that does not want grad_input (CS_STAGE_NO_GRAD_INPUT) scatters nothing: at most channels-last tables
     T2 = 16 * 16 * 256 * 256 * 4
     assert lib.cs_workspace_bytes(2, 1 | 0x10, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
