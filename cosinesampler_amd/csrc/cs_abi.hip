@@ -440,15 +440,8 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-#ifndef CS_FWD3
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
                                       pr.icl, grid, offset, output, pb.d, pb.f))));
-#else   // experiment (tools/kbench.hip): LDS-DMA gathers + register stores; faster only with warm caches
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
-        constexpr int NB = 2 < CQ ? 2 : CQ;
-        tl::point_forward3<KERNEL, CQ, NB><<<point_grid(pb), kBlock, tl::f3_lds<CQ, NB>(), pb.stream>>>(pr.icl, grid, offset, output, pb.d, pb.f);
-    }));
-#endif
     return launch_status();
 }
 

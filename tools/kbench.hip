@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../cosinesampler_amd/csrc/cs_tiled.cuh"
+#include "kbench_kernels.cuh"
 
 #define CK(x)                                                                        \
     do {                                                                             \
