@@ -11,8 +11,9 @@ N=16 C=16 H=W=256, P=2^20 points PER GPU (configs[1]; configs[4] = the same per-
 
 One step = one pass of the whole hot path over one batch of synthetic, HBM-resident inputs:
     forward (K1) -> backward (K2: grad_input + grad_grid) -> backward_backward (K3, gOutInput absent)
-    -> fused third backward (K4 + the reference's extra K3), the three input-shaped gradients
-    accumulated into one buffer and, for N>1, summed over ranks with ONE RCCL all-reduce.
+    -> fused third backward (K4 + the reference's extra K3), the three input-shaped gradients summed into one
+    buffer; for N>1 each of them is first summed over the ranks by an RCCL all-reduce that starts, asynchronously,
+    as soon as its stage is enqueued (cosinesampler_amd.dist.GradReducer) -- the step waits once, at its end.
 All calls go through the C ABI (cosinesampler_amd.ops -> libcosine_sampler_hip.so).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the slowest stage kernel(s) (HIP-event time on
@@ -34,15 +35,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 
-# what each timed stage launches at this config (names as rocprofv3 prints them, profiles/round1_kernel_stats.csv);
+# what each timed stage launches at this config (names as rocprofv3 prints them, profiles/round2_kernel_stats.csv);
 # a stage's HIP-event time is the sum of these plus the 64 MiB clear of its grad_input
 STAGE_KERNELS = {
     "forward": ["cs::tiled::pack_channels_last", "cs::tiled::point_forward<0, 4>"],
     "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward<0, 4, true>",
-                 "cs::tiled::tile_scatter<4, false>"],
-    "backward_backward": ["cs::tiled::point_bb<0, 4, false, true>", "cs::tiled::tile_scatter<4, false>"],
-    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true>", "cs::tiled::tile_scatter<4, true>"],
+                 "cs::tiled::tile_scatter<4, 0, true>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2>", "cs::tiled::tile_scatter<4, 2, false>"],
+    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true>", "cs::tiled::tile_scatter<4, 3, false>"],
 }
+
+
+def csrc_digest():
+    """Identity of the kernels the numbers belong to: sha256 over the device sources + the C ABI header."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "cosinesampler_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        h.update(name.encode())
+        h.update(open(os.path.join(base, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cosine_sampler.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(S, C, d, T):
@@ -182,6 +195,8 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20, help="P per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-helmholtz", action="store_true", help="skip the extra autograd-driven PIXEL step timing")
+    ap.add_argument("--rccl-alone", action="store_true",
+                    help="with one rank: still create the RCCL process group and run the gradient all-reduces through it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,12 +209,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
-    if world > 1:
+    # --rccl-alone: a ONE-rank RCCL group whose collectives really run (tests/test_parity_gpu.py: the communication
+    # path of the multi-GPU job, rehearsed on the single GPU a test box has)
+    use_dist = world > 1 or args.rccl_alone
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     from cosinesampler_amd import multicell_offset, ops
-    from cosinesampler_amd.dist import all_reduce_grad_
+    from cosinesampler_amd.dist import GradReducer
 
     N, C, H, P, d = 16, 16, 256, args.points, 2
     S = N * P
@@ -224,50 +243,61 @@ def main():
     ev = []
     out_keep = []
 
-    def step(record):
+    def step(record, reduce=True):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         # A fresh StepContext every step: the channels-last copy of `cells` and the point plan of
         # `grid` are rebuilt inside the timed region each step (forward pays the copy, backward the
         # plan), exactly as one CosineSampler2d.apply + its backward chain would.
         sc = ops.StepContext()
+        # every input-shaped gradient starts its sum over the ranks the moment its stage has been enqueued (RCCL's own
+        # stream, behind the producing kernels) and the step waits once, at the end: only the last one is exposed
+        red = GradReducer(even_alone=args.rccl_alone, enabled=reduce and use_dist)
         if record:
             e[0].record()
         out = ops.forward(cells, grid, off, pad, align, kern, mc, ctx=sc)
         if record:
             e[1].record()
         gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc, ctx=sc)
+        red.push(gI)
         if record:
             e[2].record()
         bbI, bbG, bbO = ops.backward_backward(None, cG, cells, grid, gOut, off, pad, align, False, kern, mc, ctx=sc)
+        red.push(bbI)
         if record:
             e[3].record()
         tI, tO = ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, pad, align, kern, mc, ctx=sc)
+        red.push(tI)
         if record:
             e[4].record()
             ev.append(e)
-        torch.add(gI, bbI, out=acc)
-        acc.add_(tI)
-        all_reduce_grad_(acc)            # the single collective of a step (no-op at N=1)
+        red.finish(out=acc)              # acc = sum over stages (and ranks) of the input-shaped gradients
         return out, gG, bbG, bbO, tO
+
+    def timed(steps, record, reduce=True):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(record, reduce)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     for _ in range(args.warmup):
         step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps, True)
+    no_reduce_ms = None
+    if use_dist:   # the same steps without the collectives: what the reduction costs the step
+        no_reduce_ms = timed(args.steps, False, reduce=False) / args.steps * 1e3
 
     stage_ms = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) for i, nm in enumerate(stage_names)}
     ab = algorithmic_bytes(S, C, d, T)
@@ -276,15 +306,19 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     total_bytes = sum(ab.values())
 
-    # HBM-side bytes of each stage from the PMC passes of tools/profile_round.sh (same command, same
-    # config), folded by tools/pmc_to_traffic.py; null when this exact config has not been profiled
-    traffic = None
+    # HBM-side bytes of the dominant stage: measured by the PMC passes of tools/profile_round.sh (same command, same
+    # config) and folded by tools/pmc_to_traffic.py -- a separate rocprofv3 run, since counters cannot be read in-process.
+    # Emitted only when that file was made from THESE kernels (digest of the device sources), else null.
+    traffic, traffic_source = None, "not measured for this build (profiles/stage_traffic.json is from other kernels or another config)"
     tpath = os.path.join(ROOT, "profiles", "stage_traffic.json")
     if P == (1 << 20) and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom)
+            tj = json.load(open(tpath))
+            if tj.get("csrc_digest") == csrc_digest():
+                traffic = tj["bytes_per_launch"].get(dom)
+                traffic_source = tj.get("source")
         except (ValueError, KeyError):
-            traffic = None
+            pass
 
     if rank == 0:
         line = {
@@ -302,15 +336,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": "2D cosine multicell zeros align_corners N=16 C=16 H=W=256 P=%d per GPU: "
                                    "forward + backward + backward_backward + fused third backward%s"
-                                   % (P, " + 1 RCCL all-reduce of grad_input (64 MiB)" if world > 1 else ""),
+                                   % (P, " + RCCL all-reduce of the grad_inputs (3 x 64 MiB, overlapped)" if use_dist else ""),
                        "samples_per_step_per_gpu": S, "sharding": "points (P) across ranks"},
             "roofline": {"bound": "hbm", "kernel": dom, "kernels": STAGE_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]},
             "pipeline_roofline_frac": total_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
             "stages_ms": stage_ms,
             "stages_frac": {k: ab[k] / (stage_ms[k] * 1e-3) / HBM_PEAK for k in stage_names},
         }
+        if use_dist:
+            line["ms_per_step_no_reduce"] = no_reduce_ms
+            line["allreduce_ms"] = ms_per_step - no_reduce_ms
+            line["reduce"] = ("3 RCCL all-reduces of 64 MiB per step (one per input-shaped gradient), each started "
+                              "asynchronously when its stage is enqueued, one wait at the end of the step")
         if world == 1 and not args.no_helmholtz:
             del out_keep[:]
             del cells, grid, gOut, hO, cG, hG, acc      # make room: the 3D config holds a 512 MiB table
@@ -327,7 +366,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, C, H)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

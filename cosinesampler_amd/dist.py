@@ -27,12 +27,53 @@ def shard_grid(grid, rank=None, world_size=None):
     return grid[..., lo:hi, :].contiguous()
 
 
-def all_reduce_grad_(grad_input, group=None, async_op=False):
-    """In-place SUM of an `input`-shaped gradient over ranks: the single collective of a step.
-    backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" works for CPU rehearsals."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_reduce_grad_(grad_input, group=None, async_op=False, even_alone=False):
+    """In-place SUM of an `input`-shaped gradient over ranks: the only kind of collective a step has.
+    backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" works for CPU rehearsals.
+    `even_alone`: issue the collective in a one-rank group too (tests: the RCCL call path runs on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size(group) == 1 and not even_alone:
         return None
     return dist.all_reduce(grad_input, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class GradReducer(object):
+    """Overlaps the reduction of the `input`-shaped gradients with the stages that follow.
+
+    A training step produces up to three of them (first, second and third backward), each ready long before the
+    step ends (at config 2: 1.8, 3.0 and 4.7 ms into a 5.3 ms step).  `push(g)` starts `g`'s sum over the ranks right
+    away -- asynchronously, on the communicator's own stream, ordered after the kernels that produced `g` -- and
+    returns at once; `finish(out=)` waits for every collective started so far (the current stream waits, the host
+    does not) and returns their sum.  Only the last gradient's reduction is left exposed: 64 MiB over xGMI.
+    Without a process group (or alone in it) it only sums."""
+
+    def __init__(self, group=None, even_alone=False, enabled=True):
+        self.group = group
+        self.even_alone = even_alone
+        self.enabled = enabled           # False: only sum locally (bench.py's "without the reduce" timing)
+        self._pending = []
+
+    def push(self, grad):
+        work = all_reduce_grad_(grad, self.group, async_op=True, even_alone=self.even_alone) if self.enabled else None
+        self._pending.append((grad, work))
+        return grad
+
+    def finish(self, out=None):
+        total = out
+        first = True
+        for grad, work in self._pending:
+            if work is not None:
+                work.wait()            # stream-ordered for RCCL; blocks for gloo
+            if total is None:
+                total = grad.clone()
+            elif first and out is not None:
+                total.copy_(grad)
+            else:
+                total.add_(grad)
+            first = False
+        self._pending = []
+        return total
 
 
 def gather_points(local, group=None):

@@ -67,10 +67,17 @@ def _worker(rank, world, port, d, q):
         lo, hi = point_range(P, rank, world)
         loc_grid = shard_grid(grid, rank, world)
         loc_out, loc_gc = loss_and_grad(cells, loc_grid, wts[..., lo:hi].contiguous())
-        all_reduce_grad_(loc_gc)                                 # the one collective
+        # the overlapped form: three input-shaped gradients, each reduced asynchronously, one wait, their sum
+        from cosinesampler_amd.dist import GradReducer
+        red = GradReducer()
+        for a in (0.5, 0.3, 0.2):
+            red.push(loc_gc * a)
+        red_total = red.finish(out=torch.empty_like(loc_gc))
+        all_reduce_grad_(loc_gc)                                 # the plain form: one collective
         out = gather_points(loc_out)
         ok = (torch.allclose(out, full_out, rtol=0, atol=0)
-              and float((loc_gc - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max()))
+              and float((loc_gc - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max())
+              and float((red_total - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max()))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -4,6 +4,8 @@
   * torch.nn.functional.grid_sample for the linear kernel (bit-exact forward),
   * size-independent properties at BASELINE.json's full sizes.
 Tolerance: max|a-b|/max|b| <= 1e-5 per tensor (helpers.REL_TOL; north_star's "within 1e-5 fp32")."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -746,3 +748,26 @@ def test_full_size_3d_smoke_properties():
     sl = slice(0, 2048)
     want = cs_oracle.forward(inp[3:4].cpu(), grid[3:4, :, :, sl].contiguous().cpu(), off[3:4].cpu(), 0, True, 2, True)
     assert_close(out[3:4, :, :, :, sl], want, "3D full-size slice vs oracle")
+
+
+def test_rccl_path_runs_on_one_gpu():
+    """The multi-GPU job's communication path -- init_process_group("nccl") (= RCCL), the asynchronous per-stage
+    all-reduces of GradReducer, the barrier and MAX-reduce of bench.py's timing -- executed for real in fresh child
+    processes on the one GPU a test box has (a one-rank group): tests/rccl_alone_child.py checks the numbers,
+    `bench.py --rccl-alone` the distributed branch of the benchmark and its extra fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_alone_child.py")], capture_output=True,
+                       text=True, timeout=300, env=dict(env, MASTER_PORT="29533"))
+    assert r.returncode == 0 and "RCCL_ALONE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-alone", "--points", "131072", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-helmholtz"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, MASTER_PORT="29534"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["ms_per_step_no_reduce"] > 0 and "allreduce_ms" in line and "RCCL" in line["reduce"]
+
