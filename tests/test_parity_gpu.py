@@ -718,13 +718,35 @@ def test_full_size_2d_properties(N, C, H, P):
         ops.force_path(0)
     assert rel_err(gI, dI) <= 1e-5 and rel_err(gG, dG) <= 1e-5
     assert rel_err(fI, dfI) <= 1e-5 and rel_err(fO, dfO) <= 1e-5
-    # 9. a slice of the full-size result against the CPU oracle (n = 5, first 4096 points)
-    sl, k = slice(0, 4096), min(5, N - 1)
-    want = cs_oracle.forward(inp[k:k + 1].cpu(), grid[k:k + 1, :, sl].contiguous().cpu(), off[k:k + 1].cpu(), 0, True, 0, True)
-    assert_close(a[k:k + 1, :, :, sl], want, "full-size slice vs oracle")
+    # 9. a slice of every p-ordered full-size result against the CPU oracle (n = 5, first 4096 points): these depend on
+    #    the slice's own points only; the input-shaped gradients (sums over all points) rest on 3.-8.
+    sl, k = slice(0, min(4096, P)), min(5, N - 1)
+    kk = slice(k, k + 1)
+    inp_k, grid_s, off_k = inp[kk].cpu(), grid[kk, :, sl].contiguous().cpu(), off[kk].cpu()
+    ps = lambda t: t[kk][..., sl].contiguous().cpu()           # (N,C,1,P) streams
+    gs = lambda t: t[kk, :, sl].contiguous().cpu()             # (N,1,P,2) grid-shaped
+    want = cs_oracle.forward(inp_k, grid_s, off_k, 0, True, 0, True)
+    assert_close(a[kk, :, :, sl], want, "full-size slice vs oracle: out")
+    _, w_gG = cs_oracle.backward(ps(gOut), inp_k, grid_s, off_k, 0, True, True, 0, True)
+    assert_close(gG[kk, :, sl], w_gG, "full-size slice vs oracle: grad_grid")
+    _, w_bbG, w_bbO = cs_oracle.backward_backward(None, gs(cG), inp_k, grid_s, ps(gOut), off_k, 0, True, False, 0, True)
+    assert_close(bbG[kk, :, sl], w_bbG, "full-size slice vs oracle: second-backward grad_grid")
+    assert_close(bbO[kk, :, :, sl], w_bbO, "full-size slice vs oracle: grad_grad_out")
+    _, w_fO = cs_oracle.bbb_fused(inp_k, grid_s, ps(gOut), gs(cG), gs(hG), ps(hO), off_k, 0, True, 0, True)
+    assert_close(fO[kk, :, :, sl], w_fO, "full-size slice vs oracle: third-backward grad_grad_out")
+    # 10. the stages of ONE step sharing a StepContext (prepared table copy and plan, the sorted grad_output copy the
+    #     first backward leaves for the walkers of the later stages) give what the independent calls above gave
+    sc = ops.StepContext()
+    s_out = ops.forward(inp, grid, off, *args, ctx=sc)
+    s_gI, s_gG = ops.backward(gOut, inp, grid, off, 0, True, True, 0, True, ctx=sc)
+    s_bbI, s_bbG, s_bbO = ops.backward_backward(None, cG, inp, grid, gOut, off, 0, True, False, 0, True, ctx=sc)
+    s_fI, s_fO = ops.bbb_fused(inp, grid, gOut, cG, hG, hO, off, 0, True, 0, True, ctx=sc)
+    for got, ref, nm in ((s_out, a, "out"), (s_gI, gI, "gI"), (s_gG, gG, "gG"), (s_bbI, bbI, "bbI"), (s_bbG, bbG, "bbG"),
+                         (s_bbO, bbO, "bbO"), (s_fI, fI, "fI"), (s_fO, fO, "fO")):
+        assert rel_err(got, ref) <= 1e-5, "shared StepContext vs independent calls: %s" % nm
 
 
-def test_full_size_3d_smoke_properties():
+def test_full_size_3d_properties():
     # BASELINE.json configs[3]: 3D smoothstep, N=8 C=8 128^3, P=2^19
     torch.manual_seed(1)
     N, C, S, P = 8, 8, 128, 1 << 19
@@ -745,9 +767,39 @@ def test_full_size_3d_smoke_properties():
     vals = [ip(gG, cG), ip(bbO, gOut), ip(bbI, inp)]
     scale = max(v[1] for v in vals)
     assert all(abs(v[0] - vals[0][0]) <= 1e-6 * scale for v in vals)
-    sl = slice(0, 2048)
-    want = cs_oracle.forward(inp[3:4].cpu(), grid[3:4, :, :, sl].contiguous().cpu(), off[3:4].cpu(), 0, True, 2, True)
-    assert_close(out[3:4, :, :, :, sl], want, "3D full-size slice vs oracle")
+    same = lambda vals: all(abs(v[0] - vals[0][0]) <= 1e-6 * max(w[1] for w in vals) for v in vals)
+    # third order at full size (3d.cu:875-1071): gGrid is linear in input and in gOut.  K8 keeps the pure second
+    # derivatives only while K7's gGrid has the mixed ones too, so the adjoint identity holds for
+    # axis-aligned cotangents (one non-zero component, same axis) -- what grad(u_xx, cells) produces
+    from helpers import axis_only
+    cGa, hG = axis_only(cG, 1), torch.randn_like(grid)
+    hGa = axis_only(hG, 1)
+    _, bbGa, _ = ops.backward_backward(None, cGa, inp, grid, gOut, off, 0, True, False, 2, True, want_grad_input=False)
+    k4I, k4O = ops.backward_backward_backward(inp, grid, gOut, cGa, hGa, off, 0, True, True, 2, True)
+    assert same([ip(bbGa, hGa), ip(k4O, gOut), ip(k4I, inp)])
+    del bbGa
+    k4I, k4O = ops.backward_backward_backward(inp, grid, gOut, cG, hG, off, 0, True, True, 2, True)
+    # ... and the fused third backward is K4 plus the grad_input of a second backward run on hO (modules_3d.py:95-100)
+    hO = torch.randn_like(gOut)
+    fI, fO = ops.bbb_fused(inp, grid, gOut, cG, hG, hO, off, 0, True, 2, True)
+    extra, _, _ = ops.backward_backward(None, cG, inp, grid, hO, off, 0, True, False, 2, True)
+    assert rel_err(fI, k4I + extra) <= 1e-5
+    assert rel_err(fO, k4O) <= 1e-6
+    del extra, k4I, k4O
+    # slices of every p-ordered result against the CPU oracle (table 3, first 2048 points)
+    sl, kk = slice(0, 2048), slice(3, 4)
+    inp_k, grid_s, off_k = inp[kk].cpu(), grid[kk, :, :, sl].contiguous().cpu(), off[kk].cpu()
+    ps = lambda t: t[kk][..., sl].contiguous().cpu()
+    gs = lambda t: t[kk, :, :, sl].contiguous().cpu()
+    want = cs_oracle.forward(inp_k, grid_s, off_k, 0, True, 2, True)
+    assert_close(out[kk, :, :, :, sl], want, "3D full-size slice vs oracle: out")
+    _, w_gG = cs_oracle.backward(ps(gOut), inp_k, grid_s, off_k, 0, True, True, 2, True)
+    assert_close(gG[kk, :, :, sl], w_gG, "3D full-size slice vs oracle: grad_grid")
+    _, w_bbG, w_bbO = cs_oracle.backward_backward(None, gs(cG), inp_k, grid_s, ps(gOut), off_k, 0, True, False, 2, True)
+    assert_close(bbG[kk, :, :, sl], w_bbG, "3D full-size slice vs oracle: second-backward grad_grid")
+    assert_close(bbO[kk, :, :, :, sl], w_bbO, "3D full-size slice vs oracle: grad_grad_out")
+    _, w_fO = cs_oracle.bbb_fused(inp_k, grid_s, ps(gOut), gs(cG), gs(hG), ps(hO), off_k, 0, True, 2, True)
+    assert_close(fO[kk, :, :, :, sl], w_fO, "3D full-size slice vs oracle: third-backward grad_grad_out")
 
 
 def test_rccl_path_runs_on_one_gpu():
