@@ -86,6 +86,20 @@ int zero_async(float *p, int64_t elems, hipStream_t s) {
     return launch_status();
 }
 
+// channels-last scratch (N,vol,CP) -> the caller's (N,C,vol)
+int unpack_cl(const float *acc, float *out, int64_t N, int64_t C, int64_t CP, int64_t vol, hipStream_t s) {
+    if ((vol & 3) == 0 && (CP & 3) == 0 && CP <= 64 && (((uintptr_t)acc | (uintptr_t)out) & 15) == 0) {
+        const int nv = cs::cl4_nv((int)CP);
+        dim3 g((unsigned)((vol + nv - 1) / nv), (unsigned)N);
+        cs::unpack_cl4<<<g, 256, cs::cl4_lds((int)CP), s>>>(acc, out, (int)C, (int)CP, vol);
+        return launch_status();
+    }
+    const int nv = cs::unpack_nv((int)C);
+    dim3 g((unsigned)((vol + nv - 1) / nv), (unsigned)N);
+    cs::unpack_channels_last<<<g, 256, (size_t)nv * (C + 1) * 4, s>>>(acc, out, (int)C, (int)CP, vol);
+    return launch_status();
+}
+
 // channel count of a channels-last copy: a whole number of float4 quads (C = 1..3 runs zero-padded to 4 in 2D)
 int64_t cpad(int64_t C) { return (C + 3) & ~(int64_t)3; }
 
@@ -221,10 +235,7 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
     }
     rc = launch_status();
     if (rc) return rc;
-    const int nv = cs::unpack_nv(pb.d.C);
-    dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, pb.d.C, pb.d.vol);
-    return launch_status();
+    return unpack_cl(acc, out_grad, pb.d.N, pb.d.C, pb.d.C, pb.d.vol, pb.stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,8 +351,15 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
 
 int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipStream_t s) {
     if (N == 0 || C == 0 || vol == 0) return CS_OK;
-    dim3 g((unsigned)((vol + 63) / 64), (unsigned)N);
     const int64_t CP = cpad(C);
+    if ((vol & 3) == 0 && CP <= 64 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {   // 16-byte accesses on both sides
+        const int nv = cs::cl4_nv((int)CP);
+        const size_t shm = cs::cl4_lds((int)CP);
+        dim3 g((unsigned)((vol + nv - 1) / nv), (unsigned)N);
+        cs::pack_cl4<<<g, 256, shm, s>>>(in, out, (int)C, (int)CP, vol);
+        return launch_status();
+    }
+    dim3 g((unsigned)((vol + 63) / 64), (unsigned)N);
     tl::pack_channels_last<<<g, 256, (size_t)CP * 65 * 4, s>>>(in, out, (int)C, (int)CP, vol);
     return launch_status();
 }
@@ -688,10 +706,7 @@ size_t rcl_lds(int C, int mode) {
 }
 // accumulator -> caller's layout
 int rcl_finish(const Problem &pb, const float *acc, float *out_grad) {
-    const int nv = cs::unpack_nv(pb.d.C);
-    dim3 g((unsigned)((pb.d.vol + nv - 1) / nv), (unsigned)pb.d.N);
-    cs::unpack_channels_last<<<g, 256, (size_t)nv * (pb.d.C + 1) * 4, pb.stream>>>(acc, out_grad, pb.d.C, (int)cpad(pb.d.C), pb.d.vol);
-    return launch_status();
+    return unpack_cl(acc, out_grad, pb.d.N, pb.d.C, cpad(pb.d.C), pb.d.vol, pb.stream);
 }
 int rcl_accumulator(const Problem &pb, Carve &ws, float *&acc) {
     const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
