@@ -100,12 +100,18 @@ int unpack_cl(const float *acc, float *out, int64_t N, int64_t C, int64_t CP, in
     return launch_status();
 }
 
-// channel count of a channels-last copy: a whole number of float4 quads (C = 1..3 runs zero-padded to 4 in 2D)
-int64_t cpad(int64_t C) { return (C + 3) & ~(int64_t)3; }
+// channel count of a channels-last copy: 1, 2, 4, 8 or 16 float4 quads -- the counts the fast kernels are built for.
+// Other channel counts run zero-padded up to the next one (C = 1..3 as 4, 5..7 as 8, 9..15 as 16, 17..31 as 32): the
+// reference takes any C in one loop (2d.cu:340-354), and the direct kernels' scattered atomics are 30-100x slower.
+int64_t cpad(int64_t C) {
+    int64_t q = 1;
+    while (q * 4 < C) q *= 2;
+    return q * 4;
+}
 
 // channel-count dispatch of the fast paths: CQ = cpad(C)/4 in {1, 2, 4}
 #define CS_DISPATCH_CQ(C_, ...)                                               \
-    switch (((C_) + 3) / 4) {                                                 \
+    switch (cpad(C_) / 4) {                                                   \
         case 1:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
         case 2:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
         default: { constexpr int CQ = 4; __VA_ARGS__; } break;                \
@@ -113,7 +119,7 @@ int64_t cpad(int64_t C) { return (C + 3) & ~(int64_t)3; }
 
 // the 2D tiled path also takes 32 channels (8 quads); the 3D channels-last kernels stop at 16
 #define CS_DISPATCH_CQT(C_, ...)                                              \
-    switch (((C_) + 3) / 4) {                                                 \
+    switch (cpad(C_) / 4) {                                                   \
         case 1:  { constexpr int CQ = 1; __VA_ARGS__; } break;                \
         case 2:  { constexpr int CQ = 2; __VA_ARGS__; } break;                \
         case 4:  { constexpr int CQ = 4; __VA_ARGS__; } break;                \
@@ -248,14 +254,13 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 bool tiled_applies(int dim, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     int mode = g_force_path.load(std::memory_order_relaxed);
     if (mode == 1 || dim != 2) return false;
-    if (!(C <= 4 || C == 8 || C == 16 || C == 32)) return false;   // C = 1..3: zero-padded to one quad
+    if (C > 32) return false;                             // other counts run zero-padded to 4, 8, 16 or 32 (cpad)
     int64_t S = N * P;
     if (S <= 0 || S >= (int64_t)0xFFFFFFF0ll) return false;
     int64_t ntx = (W + 1 + tl::TX - 1) / tl::TX, nty = (H + 1 + tl::TY - 1) / tl::TY;
     if (ntx * nty > 12288) return false;                 // tile histogram lives in LDS (48 KiB)
     if (N * ntx * nty >= (int64_t)INT32_MAX) return false;
     if (N > 65535 || H * W * C >= ((int64_t)1 << 31)) return false;   // gridDim.y = N; 32-bit node offsets
-    if (P > ((int64_t)1 << 24)) return false;                          // plan keys pack (p << 8) | cell
     if (mode >= 2) return true;
     return S >= kTiledMinSamples;
 }
@@ -272,7 +277,7 @@ int plan_chunk(int64_t N, int64_t P, int64_t bins) {
 
 struct PlanLayout {
     int ntx, nty, ntiles, chunks, chunk, dense;
-    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, off_G, bytes;
+    size_t off_sorted, off_key, off_tile_begin, off_cell_begin, off_block_hist, off_totals, off_bsum, off_G, off_cellb, bytes;
 };
 
 // Crowded tables (the reference's own test shapes: 96 tables of 16x16 cells, 10^5 points): the plan bins by cell
@@ -303,6 +308,7 @@ PlanLayout plan_layout(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
     L.off_totals = o;     o += align256((size_t)N * L.ntiles * 4);
     L.off_bsum = o;       o += align256(((size_t)N * L.ntiles / 1024 + 3) * 4);
     L.off_G = o;          o += L.dense ? 0 : align256((size_t)S * cpad(C) * 4);   // Plan::Gs (walker plans only)
+    L.off_cellb = o;      o += (L.dense || P <= ((int64_t)1 << 24)) ? 0 : align256((size_t)S);   // keys no longer hold the cell
     L.bytes = o;
     return L;
 }
@@ -325,6 +331,7 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.cell_begin = (uint32_t *)(b + L.off_cell_begin);
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
     p.Gs = L.dense ? nullptr : (float *)(b + L.off_G);
+    p.cellb = (L.off_cellb == L.bytes || L.dense) ? nullptr : (uint8_t *)(b + L.off_cellb);
     p.ntx = L.ntx;
     p.nty = L.nty;
     p.ntiles = L.ntiles;
@@ -582,7 +589,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     const int mode = g_force_path.load(std::memory_order_relaxed);
-    if (mode == 1 || dim != 3 || !(C <= 4 || C == 8 || C == 16)) return false;   // C = 1..3: zero-padded to one quad
+    if (mode == 1 || dim != 3 || C > 16) return false;   // other counts run zero-padded to 4, 8 or 16 (cpad)
     if (N * P >= ((int64_t)1 << 31) || N * vol >= ((int64_t)1 << 31) || vol * cpad(C) >= ((int64_t)1 << 31)) return false;
     if (N > 65535) return false;                               // pack / unpack launch with gridDim.y = N
     return mode >= 2 || N * P >= (1 << 16);   // (global node ids of the fused scatter are 32-bit)
@@ -596,7 +603,7 @@ constexpr int64_t kDense3MaxCells = 40000;
 bool dense3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (g_force_path.load(std::memory_order_relaxed) == 3) return false;   // testing: row atomics only
     const int64_t cells = (W + 1) * (H + 1) * (D + 1);
-    return (C <= 4 || C == 8 || C == 16) && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
+    return C <= 16 && cells <= kDense3MaxCells && P >= 8 * cells && N * cells < (int64_t)INT32_MAX &&
            N * P < (int64_t)0xFFFFFFF0ll && N <= 65535;
 }
 struct Plan3Layout {
@@ -624,6 +631,7 @@ tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
     tl::Plan p;
     p.sorted = (uint32_t *)(b + L.off_sorted);
     p.key = nullptr;
+    p.cellb = nullptr;
     p.Gs = nullptr;
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
     p.cell_begin = nullptr;

@@ -20,14 +20,14 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 // the 4 channels of a quad of a channel-major stream; cv = how many of them exist (C = 1..3 runs zero-padded)
 __device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
     float4 r;
-    r.x = __builtin_nontemporal_load(src);
+    r.x = cv > 0 ? __builtin_nontemporal_load(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
     r.y = cv > 1 ? __builtin_nontemporal_load(src + P) : 0.0f;
     r.z = cv > 2 ? __builtin_nontemporal_load(src + 2 * P) : 0.0f;
     r.w = cv > 3 ? __builtin_nontemporal_load(src + 3 * P) : 0.0f;
     return r;
 }
 __device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o, int cv) {
-    __builtin_nontemporal_store(o.x, dst);
+    if (cv > 0) __builtin_nontemporal_store(o.x, dst);
     if (cv > 1) __builtin_nontemporal_store(o.y, dst + P);
     if (cv > 2) __builtin_nontemporal_store(o.z, dst + 2 * P);
     if (cv > 3) __builtin_nontemporal_store(o.w, dst + 3 * P);

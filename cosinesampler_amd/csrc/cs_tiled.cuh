@@ -51,7 +51,9 @@ constexpr int CHUNK = 16384;               // samples per plan workgroup, at mos
 struct Plan {
     uint32_t *sorted;      // [S]  sorted position (by n, tile, cell) -> sample id n*P+p; only the first
                            //      tile_begin[N*ntiles] entries are defined (samples touching no node are dropped)
-    uint32_t *key;         // [S]  scratch: tile-sorted slot -> (p << 8) | local cell id   (needs P <= 2^24)
+    uint32_t *key;         // [S]  scratch: tile-sorted slot -> (p << 8) | local cell id; with more than 2^24 points per
+                           //      table (`cellb` set): the point index alone, the cell id in cellb[slot]
+    uint8_t *cellb;        // [S]  scratch, only when P > 2^24
     uint32_t *tile_begin;  // [N*ntiles + 1]      first sorted position of every tile bucket
     uint32_t *cell_begin;  // [N*ntiles*(CELLS+1)] bucket-relative first position of every cell of every tile
     uint32_t *block_hist;  // [N*chunks*ntiles] scratch
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
             if (q.valid) {
                 uint32_t r = atomicAdd(&cursor[q.bin(pl)], 1u);
                 if (pl.dense) pl.sorted[r] = (uint32_t)s;                 // bins are cells: this is the final order
+                else if (pl.cellb) { pl.key[r] = (uint32_t)p; pl.cellb[r] = (uint8_t)q.cell; }
                 else pl.key[r] = ((uint32_t)p << 8) | (uint32_t)q.cell;   // one scattered word per sample
             }
         }
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     uint32_t *cbeg = pl.cell_begin + t * (CELLS + 1);
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) atomicAdd(&cnt[pl.key[j] & 0xFFu], 1u);
+    for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) atomicAdd(&cnt[pl.cellb ? pl.cellb[j] : (pl.key[j] & 0xFFu)], 1u);
     __syncthreads();
     uint32_t v = cnt[threadIdx.x];
     scan[threadIdx.x] = v;
@@ -253,9 +256,10 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     __syncthreads();
     const uint32_t sbase = (uint32_t)(t / pl.ntiles) * (uint32_t)P;   // n * P
     for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) {
-        uint32_t k = pl.key[j];
-        uint32_t pos = atomicAdd(&cnt[k & 0xFFu], 1u);
-        pl.sorted[b0 + pos] = sbase + (k >> 8);
+        const uint32_t k = pl.key[j];
+        const uint32_t cell = pl.cellb ? pl.cellb[j] : (k & 0xFFu), pp = pl.cellb ? k : (k >> 8);
+        uint32_t pos = atomicAdd(&cnt[cell], 1u);
+        pl.sorted[b0 + pos] = sbase + pp;
     }
 }
 
@@ -355,7 +359,7 @@ __device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs,
 // the 4 channels 4q..4q+3 of a channel-major stream; channels >= cv do not exist (C < 4 runs zero-padded as CQ = 1)
 __device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
     float4 r;
-    r.x = ld_stream(src);
+    r.x = cv > 0 ? ld_stream(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
     r.y = cv > 1 ? ld_stream(src + P) : 0.0f;
     r.z = cv > 2 ? ld_stream(src + 2 * P) : 0.0f;
     r.w = cv > 3 ? ld_stream(src + 3 * P) : 0.0f;
@@ -453,7 +457,7 @@ __device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4
     for (int q = 0; q < CQ; ++q) {
         float *p = dst + (int64_t)(4 * q) * P;
         const int cv = C - 4 * q;
-        st_stream_wt(p, o[q].x);
+        if (cv > 0) st_stream_wt(p, o[q].x);
         if (cv > 1) st_stream_wt(p + P, o[q].y);
         if (cv > 2) st_stream_wt(p + 2 * P, o[q].z);
         if (cv > 3) st_stream_wt(p + 3 * P, o[q].w);

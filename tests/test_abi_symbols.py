@@ -62,7 +62,10 @@ def test_loader_binds_and_reports_errors_without_gpu():
     assert lib.cs_workspace_bytes(3, 0, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == 0
     assert lib.cs_pack_bytes(3, 8, 8, 128, 128, 128, 1 << 19) == T3
     assert lib.cs_workspace_bytes(2, 3, 16, 64, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 64 * 256 * 256 * 4
-    assert lib.cs_workspace_bytes(2, 1, 16, 5, 1, 256, 256, 1 << 20, 0, 0, 0) == 0
+    # 5 channels run zero-padded as 8 on the tiled path: table copy (8 ch), plan, rows of 8 + 4 floats
+    assert lib.cs_workspace_bytes(2, 1, 16, 5, 1, 256, 256, 1 << 20, 0, 0, 0) == (
+        16 * 8 * 256 * 256 * 4 + lib.cs2d_plan_bytes(16, 5, 256, 256, 1 << 20) + (16 << 20) * 48)
+    assert lib.cs_workspace_bytes(2, 1, 16, 33, 1, 256, 256, 1 << 20, 0, 0, 0) == 0     # beyond 32 channels: direct kernels
     assert lib.cs_workspace_bytes(2, 1, 1, 16, 1, 32, 32, 1024, 0, 0, 0) == 0
     # argument validation happens before any device work: callable without a GPU
     rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, None, None, 0, None)

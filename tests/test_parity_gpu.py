@@ -101,6 +101,12 @@ TILED_CASES += [(1, 0, 0, True, True), (2, 0, 0, True, True), (2, 2, 1, False, F
                 (3, 0, 0, False, True)]
 
 
+# every other channel count runs zero-padded up to the next supported one (5..7 as 8, 9..15 as 16, 17..31 as 32): the
+# reference loops over any C (2d.cu:340-354)
+TILED_CASES += [(5, 0, 0, True, True), (6, 2, 1, False, False), (7, 1, 2, True, True), (12, 0, 0, True, True),
+                (12, 2, 2, False, True), (24, 0, 0, True, True), (31, 0, 1, True, False)]
+
+
 @pytest.mark.parametrize("C,ke,pad,align,mc", TILED_CASES)
 @pytest.mark.parametrize("shared", [False, True])
 def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
@@ -132,7 +138,8 @@ def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
 
 ROW_CASES = [(3, 8, 0, 0, True, True), (3, 8, 2, 0, True, True), (3, 2, 1, 1, False, False), (3, 16, 2, 2, True, False),
              (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False),
-             (3, 3, 0, 0, True, True), (3, 1, 2, 1, True, False)]   # 3D with 1..3 channels: one zero-padded quad
+             (3, 3, 0, 0, True, True), (3, 1, 2, 1, True, False),   # 3D with 1..3 channels: one zero-padded quad
+             (3, 5, 0, 0, True, True), (3, 6, 2, 1, False, True), (3, 12, 0, 0, True, True)]   # padded to 8 / 16
 
 
 class _Shared(object):
@@ -657,12 +664,15 @@ def _full_size_inputs(N=16, C=16, H=256, P=1 << 20):
     return inp, grid
 
 
-@pytest.mark.parametrize("N,C,H,P", [(16, 16, 256, 1 << 20), (96, 4, 16, 100000), (1, 4, 256, 1 << 24), (2, 2, 64, 1 << 22)])
+@pytest.mark.parametrize("N,C,H,P", [(16, 16, 256, 1 << 20), (96, 4, 16, 100000), (1, 4, 256, 1 << 24), (2, 2, 64, 1 << 22),
+                                     (1, 4, 96, (1 << 24) + 1), (2, 12, 128, 1 << 20)])
 def test_full_size_2d_properties(N, C, H, P):
     """At full size the oracle is too slow; check identities that do not depend on size:
        partition of unity, linearity, and the adjoint identities linking each stage pair.
        BASELINE config 2 (tile walkers), the reference test scripts' own shapes (crowded tables: wave per cell), the
-       largest P the plan's packed keys allow (2^24 points of one table), and a padded 2-channel crowded table."""
+       largest P the plan's packed keys hold (2^24 points of one table) and one point more (separate cell bytes; the
+       reference takes any size through its 64-bit index instantiation, 2d.cu:920-933), a padded 2-channel crowded
+       table and a 12-channel table (runs padded to 16)."""
     inp, grid = _full_size_inputs(N, C, H, P)
     off = multicell_offset(N, True, DEV)
     args = (0, True, 0, True)

@@ -50,13 +50,13 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared):
 bad = 0
 for case in range(cases):
     d = rng.choice([2, 2, 3])
-    C = rng.choice([1, 2, 3, 4, 5, 8, 16, 32] if d == 2 else [1, 2, 3, 4, 8, 16, 6])
+    C = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 31, 32, 33] if d == 2 else [1, 2, 3, 4, 5, 6, 8, 12, 16, 17])
     N = rng.choice([1, 2, 3, 5])
     sp = tuple(rng.choice([2, 3, 5, 16, 17, 18, 33, 40]) for _ in range(d)) if d == 2 else \
         tuple(rng.choice([2, 3, 5, 8, 9, 16]) for _ in range(d))
     P = rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3001, 5000, 20000])
     pad, align, ke, mc = rng.choice([0, 1, 2]), rng.choice([True, False]), rng.choice([0, 1, 2]), rng.choice([True, False])
-    force = rng.choice([0, 1, 2, 2, 2, 3])
+    force = rng.choice([0, 1, 2, 2, 2, 3, 4])
     shared = rng.choice([True, False])
     g = torch.Generator().manual_seed(seed * 100003 + case)
     inp = torch.rand((N, C) + sp, generator=g)
