@@ -15,7 +15,7 @@ _c_sz = ctypes.c_size_t
 class CotangentLayout(ctypes.Structure):
     """cs_cotangent_layout (include/cosine_sampler.h): n-strides, in elements, of grad_output / grad_out_ggout."""
     _fields_ = [("grad_output_stride_n", ctypes.c_int64), ("grad_out_ggout_stride_n", ctypes.c_int64),
-                ("sorted_grad_output_valid", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("sorted_grad_output_valid", ctypes.c_int32), ("leave_sorted_grad_output", ctypes.c_int32)]
 
 
 # name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, [layout*, backward stages only],

@@ -472,7 +472,7 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
 
 int tiled_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
                    float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
-                   size_t workspace_bytes) {
+                   size_t workspace_bytes, bool g_leave) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without grad_input nothing is scattered: no plan, no fat rows -- the point kernel gathers and is all there is
@@ -492,14 +492,14 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
                                       gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
-    // a caller's plan outlives this call: leave the sorted copy of grad_output in it for the later stages' walkers
-    if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, grad_input);
+    // a caller's plan outlives this call: when asked, leave the sorted copy of grad_output in it for later stages' walkers
+    if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, grad_input);
     return launch_tile_scatter<0>(pb, pr.plan, fat, grad_input);
 }
 
 int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *input, const float *grid,
              const float *gOut, const float *offset, float *gInput, float *gGrid, float *ggOut,
-             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted) {
+             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted, bool g_leave) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
@@ -534,13 +534,13 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     rc = launch_status();
     if (rc || !gInput) return rc;
     if (lean) return launch_tile_scatter<2>(pb, pr.plan, fat, gInput);
-    if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
+    if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
     return launch_tile_scatter<0>(pb, pr.plan, fat, gInput);
 }
 
 int tiled_bbb(const Problem &pb, const float *input, const float *grid, const float *gOut, const float *cG,
               const float *hG, const float *hO, const float *offset, float *gInput, float *ggOut,
-              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted) {
+              const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted, bool g_leave) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
@@ -572,14 +572,14 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         if (rc) return rc;
         rc = launch_status();
         if (rc) return rc;
-        if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<1, true>(pb, pr.plan, fat, gInput);
+        if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<1, true>(pb, pr.plan, fat, gInput);
         return launch_tile_scatter<1>(pb, pr.plan, fat, gInput);
     } else {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
                                           pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
-        if (pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
+        if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
         return launch_tile_scatter<0>(pb, pr.plan, fat, gInput);
     }
 }
@@ -978,8 +978,8 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
-    bool g_sorted = false;                                                                                        \
-    (void)g_sorted;                                                                                               \
+    bool g_sorted = false, g_leave = false;                                                                       \
+    (void)g_sorted; (void)g_leave;                                                                                \
     const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \
     (void)tiled; (void)rows; (void)input_cl; (void)plan; (void)workspace; (void)workspace_bytes;              \
     /* The direct kernels could gather from the channels-last copy too (Dims::tab_ns/tab_cs), but with   \
@@ -994,6 +994,7 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         pb.d.go_ns = layout->grad_output_stride_n;                                                   \
         pb.d.ho_ns = layout->grad_out_ggout_stride_n;                                                \
         g_sorted = layout->sorted_grad_output_valid != 0;                                            \
+        g_leave = layout->leave_sorted_grad_output != 0;                                             \
     }
 
 // zero-element tensors legitimately come with null data pointers
@@ -1019,7 +1020,7 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     CS_NEED(grad_output, input, grid, offset, grad_grid)
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
-                              workspace_bytes);
+                              workspace_bytes, g_leave);
     if (rows && grad_input) {
         int rc = run_backward<2>(pb, grad_output, table_, grid, offset, nullptr, grad_grid);
         if (rc) return rc;
@@ -1044,7 +1045,7 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
     if (tiled && !exact_ci)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
-                        grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
+                        grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
     if (via_rows) {
         int rc = run_bb<2>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
@@ -1067,7 +1068,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
-                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
+                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -1090,7 +1091,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
-                         grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted);
+                         grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);
@@ -1208,9 +1209,9 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
-    bool g_sorted = false;
+    bool g_sorted = false, g_leave = false;
     CS_LAYOUT()
-    (void)g_sorted;
+    (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
@@ -1222,9 +1223,9 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     Problem pb;
     int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
-    bool g_sorted = false;
+    bool g_sorted = false, g_leave = false;
     CS_LAYOUT()
-    (void)g_sorted;
+    (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
     return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }

@@ -140,7 +140,9 @@ def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multice
         raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
     cfg = _Config(padding_mode, align_corners, kernel, multicell)
     offset = multicell_offset(input.shape[0], multicell, input.device)
-    step = ops.StepContext()   # channels-last input copy + point plan, shared by this call's backward chain
+    # channels-last input copy + point plan, shared by this call's backward chain; which grad_output's sorted copy is
+    # worth leaving in the plan is decided from the nodes that announce themselves (StepContext.expect)
+    step = ops.StepContext(reuse_grad_output=False)
     output = _as(ops.forward(_f32(input), _f32(grid), offset, cfg.pad, cfg.align_corners, cfg.kernel,
                              cfg.multicell, ctx=step), input)
     ctx.save_for_backward(input, grid)
@@ -154,7 +156,10 @@ def _backward(ctx, grad_out):
     input, grid = ctx.saved_tensors
     if grad_out is None:
         return None, None, None, None, None, None
-    d_input, d_grid = _SamplerBackward.apply(input, grid, ops.keep_expanded(grad_out), ctx.offset, ctx.cfg,
+    grad_out = ops.keep_expanded(grad_out)
+    if torch.is_grad_enabled():        # create_graph: the node made here may run a scatter stage on grad_out later
+        ctx.step.expect(_f32(grad_out))
+    d_input, d_grid = _SamplerBackward.apply(input, grid, grad_out, ctx.offset, ctx.cfg,
                                              _engine_wants(ctx, 0), ctx.step)
     return d_input, d_grid, None, None, None, None
 
@@ -210,6 +215,8 @@ class _SamplerBackward(Function):
         input, grid, gOut = ctx.saved_tensors
         if gOutInput is None and gOutGrid is None:
             return None, None, None, None, None, None, None
+        if torch.is_grad_enabled():    # create_graph: a third backward through the node made here scatters with gOut again
+            ctx.step.expect(_f32(gOut))
         gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
                                                               ctx.offset, ctx.cfg, ctx.step, _engine_wants(ctx, 0))
         return gInput, gGrid, ggOut, None, None, None, None

@@ -105,14 +105,26 @@ class StepContext(object):
     and dropped with the context.  The autograd Functions create one per forward call, so nothing
     outlives the graph it belongs to; pass `ctx=None` to let every stage work from scratch."""
 
-    def __init__(self):
+    def __init__(self, reuse_grad_output=True):
         self._cl = None
         self._cl_key = None
         self._plan = None
         self._plan_key = None
-        # whose cell-sorted copy the plan holds (include/cosine_sampler.h, cs_cotangent_layout.sorted_grad_output_valid):
-        # left there by the first stage that scatters, streamed by the later ones
+        # Whose cell-sorted copy the plan holds (include/cosine_sampler.h, cs_cotangent_layout.sorted_grad_output_valid)
+        # and when a stage is asked to leave one (leave_sorted_grad_output: +0.25 ms at config 2, repaid by the next
+        # stage that streams it).  reuse_grad_output=True -- a caller driving the stages of one step itself (bench.py,
+        # the reference's pybind use): every backward stage is handed the same grad_output, the first one that
+        # scatters leaves the copy.  False -- the autograd layer: the engine interleaves nodes with different
+        # grad_outputs (a Helmholtz step: five scatter stages, four different tensors), so a copy is left only for a
+        # tensor that `expect()` has announced at least twice.
+        self.reuse_grad_output = reuse_grad_output
+        self._expected = {}
         self._sorted_go = None
+
+    def expect(self, grad_output):
+        """The autograd layer announces that a node holding this grad_output exists and will hand it to a scatter stage."""
+        k = self._ckey(grad_output)
+        self._expected[k] = self._expected.get(k, 0) + 1
 
     @staticmethod
     def _key(t):
@@ -183,16 +195,19 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
         tail = (_ptr(cl), _ptr(plan), _ptr(ws), need, stream)
         if stage != "forward":
             CP = shape[1] * P
-            go_key, g_valid = None, 0
+            go_key, g_valid, g_leave = None, 0, 0
             if plan is not None:
                 go_key = ctx._ckey(grad_output)
                 g_valid = int(ctx._sorted_go == go_key)
-            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid, 0)
+                if not g_valid:
+                    g_leave = int(ctx.reuse_grad_output or ctx._expected.get(go_key, 0) >= 2)
+            layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
+                                          g_leave)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
-    if stage != "forward" and plan is not None:   # a stage that was handed a plan scatters: the plan now holds this one
+    if stage != "forward" and plan is not None and g_leave:   # the plan now holds this one's sorted copy
         ctx._sorted_go = go_key
 
 

@@ -81,7 +81,11 @@ typedef struct cs_cotangent_layout {
      * fetching them again.  The library cannot check (the bytes live in device memory): set it only if an earlier
      * call with this plan was given this very tensor, unchanged, and a non-NULL grad_input.  Zero is always safe. */
     int32_t sorted_grad_output_valid;
-    int32_t reserved;
+    /* Non-zero: a stage that fetches grad_output's rows by sample id anyway should also leave them in the plan in
+     * sorted order (one more sequential 4*N*C*P-byte write: +0.25 ms at N=16 C=16 P=2^20) because a later stage will be
+     * called with sorted_grad_output_valid.  Worth it from the second use on; a stage that does not leave its copy does
+     * not touch the one the plan holds. */
+    int32_t leave_sorted_grad_output;
 } cs_cotangent_layout;
 
 int cs_abi_version(void);
