@@ -67,8 +67,12 @@ int launch_status() {
     return e == hipSuccess ? CS_OK : (int)e;
 }
 
-// A kernel, not hipMemsetAsync: as a HIP-graph node the runtime's memset was seen to be skipped on a replay
-// (tests/test_parity_gpu.py::test_stages_can_be_captured_in_a_hip_graph), kernel nodes replay faithfully.
+// A kernel, not hipMemsetAsync: in round 1 (ROCm 7.2, HIP runtime 70226015) a memset node inside a captured stage was
+// seen to be skipped on a replay (tests/test_parity_gpu.py::test_stages_can_be_captured_in_a_hip_graph); kernel nodes
+// replay faithfully.  The minimal form of it -- memset + one kernel captured, replayed 8 times at 1 / 64 / 512 MiB
+// (tools/memset_graph_repro.hip, profiles/round2_memset_graph_repro.txt) -- does NOT reproduce the skip on the same
+// runtime, so the cause may have been the capture of a memset between kernels of this library rather than memset nodes
+// as such; the kernel costs the same (11 us per 64 MiB) and stays until that is understood.
 __global__ __launch_bounds__(256) void zero_fill(float *__restrict__ p, int64_t elems) {
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < elems; i += stride) {

@@ -833,3 +833,42 @@ def test_rccl_path_runs_on_one_gpu():
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["ms_per_step_no_reduce"] > 0 and "allreduce_ms" in line and "RCCL" in line["reduce"]
 
+
+def test_integration_stub_from_the_document():
+    """INTEGRATION.md, Option A: the ctypes stand-in for the reference's pybind module `_cosine_2d` -- the code block is
+    taken from the document as it stands, executed, and its four functions (the reference's names and argument order,
+    2d.cpp:130-135) are compared with cosinesampler_amd.ops on the GPU."""
+    import re
+    import types
+    from cosinesampler_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# cosine_sampler_2d/_cosine_2d\.py.*?)```", text, re.S)
+    assert m, "Option A code block not found"
+    os.environ["COSINESAMPLER_LIB"] = build.LIB
+    try:
+        stub = types.ModuleType("_cosine_2d")
+        exec(compile(m.group(1), "INTEGRATION.md:_cosine_2d.py", "exec"), stub.__dict__)
+    finally:
+        del os.environ["COSINESAMPLER_LIB"]
+    N, C, P = 3, 16, 40000
+    t = _case(2, N, C, (48, 40), P, seed=99, spread=1.1)
+    off = offsets(N, True).to(DEV)
+    inp, grid, gO, cG, hG, cI = (_g(t[k]) for k in ("inp", "grid", "gOut", "cG", "hG", "cI"))
+    out = stub.forward(inp, grid, off, 0, True, 0, True)
+    assert torch.equal(out, ops.forward(inp, grid, off, 0, True, 0, True))
+    gi, gg = stub.backward(gO, inp, grid, off, 0, True, True, 0, True)
+    w_gi, w_gg = ops.backward(gO, inp, grid, off, 0, True, True, 0, True)
+    assert_close(gi, w_gi, "stub backward grad_input")
+    assert torch.equal(gg, w_gg)
+    assert stub.backward(gO, inp, grid, off, 0, True, False, 0, True)[0] is None
+    for irg in (True, False):
+        got = stub.backward_backward(cI if irg else torch.zeros(1), cG, inp, grid, gO, off, 0, True, irg, 0, True)
+        want = ops.backward_backward(cI if irg else None, cG, inp, grid, gO, off, 0, True, irg, 0, True)
+        for a, b, nm in zip(got, want, ("gInput", "gGrid", "ggOut")):
+            assert_close(a, b, "stub backward_backward(%s) %s" % (irg, nm))
+    got = stub.backward_backward_backward(inp, grid, gO, cG, hG, off, 0, True, True, 0, True)
+    want = ops.backward_backward_backward(inp, grid, gO, cG, hG, off, 0, True, True, 0, True)
+    assert_close(got[0], want[0], "stub third backward gInput")
+    assert_close(got[1], want[1], "stub third backward ggOut")
+
