@@ -1,34 +1,79 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collections (gpurun_out/pmc_<tag>_*/) into
-profiles/<tag>_pmc_summary.json and profiles/stage_traffic.json (HBM-side bytes per launch of each
-bench stage = sum over the kernels that stage launches).  Counters are reported raw:
-bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, no gfx950 read-side correction applied (our stream reads are
-4 B/lane and the gathers are 16 B/lane from scattered lines -- neither is the calibrated 16 B/lane
-coalesced pattern of MI355X_MICROARCH.md, whose FETCH_SIZE reads exactly half the bytes; the true
-read traffic therefore lies between the raw figure and twice it)."""
+"""Fold the rocprofv3 --pmc passes of tools/profile_round.sh (gpurun_out/pmc_<tag>_<i>/) into
+profiles/<tag>_pmc_summary.json (per kernel) and profiles/stage_traffic.json (HBM-side bytes per launch of each bench stage
+= sum over the kernels that stage launches), stamped with the digest of the device sources so that bench.py only quotes
+it for the kernels it was measured on.
+
+Three figures per kernel, all per launch:
+  raw        (FETCH_SIZE + WRITE_SIZE) * 1024                     what rocprofv3 prints
+  corrected  (2 * FETCH_SIZE + WRITE_SIZE) * 1024                 /opt/skills/guides/MI355X_MICROARCH.md section HBM: on gfx950
+             FETCH_SIZE tallies the 128-byte read requests at 64 bytes; WRITE_SIZE is exact.  THIS is `roofline.traffic`.
+  by_size    32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)
+             the fabric requests counted by their own size counters: an independent check of the correction (all our
+             kernels' reads turn out to be 128-byte requests, streams, gathers and row fetches alike).
+    python tools/pmc_to_traffic.py [tag]
+"""
 import collections, csv, glob, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
-    files = sorted(glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c)), key=os.path.getmtime)
-    for f in files[-1:]:                      # the newest collection only
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ = {k: {c: {"launches": len(x), "per_launch": x[-1]} for c, x in v.items()} for k, v in agg.items() if "cs::" in k}
-json.dump(summ, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1, sort_keys=True)
-def kb(kname):
-    for k, v in summ.items():
-        if k.startswith(kname):
-            return (v.get("FETCH_SIZE", {}).get("per_launch", 0) + v.get("WRITE_SIZE", {}).get("per_launch", 0)) * 1024
-    return 0
-T = 16 * 16 * 256 * 256 * 4
-plan = sum(kb("cs::tiled::" + k) for k in ("plan_count", "plan_scan_chunks", "plan_scan_tiles", "plan_scatter", "plan_tile_sort"))
-stage = {
-    "forward": kb("cs::tiled::pack_channels_last") + kb("cs::tiled::point_forward"),
-    "backward": plan + kb("cs::tiled::point_backward<") + kb("cs::tiled::tile_scatter<4, false>") + T,
-    "backward_backward": kb("cs::tiled::point_bb<") + kb("cs::tiled::tile_scatter<4, false>") + T,
-    "bbb_fused": kb("cs::tiled::point_bbb<") + kb("cs::tiled::tile_scatter<4, true>") + T,
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % tag, "*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "cs::" in k or "zero_fill" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summ = {}
+for k, v in agg.items():
+    c = {name: vals[-1] for name, vals in v.items()}          # the last launch of the run (steady state)
+    d = {"launches_seen": max(len(x) for x in v.values()), "counters": c}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        d["raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        d["corrected"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+    if "TCC_EA0_RDREQ_128B_sum" in c and "TCC_EA0_WRREQ_sum" in c:
+        d["by_size"] = (32 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * c.get("TCC_EA0_RDREQ_64B_sum", 0)
+                        + 128 * c["TCC_EA0_RDREQ_128B_sum"] + 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0)
+                        + 32 * (c["TCC_EA0_WRREQ_sum"] - c.get("TCC_EA0_WRREQ_64B_sum", 0)))
+    summ[k] = d
+json.dump(summ, open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
+
+
+def total(prefixes, field):
+    t = 0.0
+    for pre in prefixes:
+        hit = [v for k, v in summ.items() if k.startswith(pre)]
+        if not hit:
+            print("warning: no kernel named", pre, file=sys.stderr)
+        for v in hit:
+            t += v.get(field, 0.0)
+    return t
+
+
+T = 16 * 16 * 256 * 256 * 4      # the zero-fill of one grad_input (the launches of zero_fill are not told apart by stage)
+plan = ["cs::tiled::plan_count", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiled::plan_scatter",
+        "cs::tiled::plan_tile_sort"]
+stages = {
+    "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4>"],
+    "backward": plan + ["cs::tiled::point_backward<0, 4, true>", "cs::tiled::tile_scatter<4, 0, true>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2>", "cs::tiled::tile_scatter<4, 2, false>"],
+    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true>", "cs::tiled::tile_scatter<4, 3, false>"],
+    # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
+    "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2>"],
+    "3d_backward": ["cs::cl::backward<3, 2, 2, 1>", "cs::unpack_cl4"],
+    "3d_backward_backward": ["cs::cl::backward_backward<3, 2, 2, false, 1>", "cs::unpack_cl4"],
+    "3d_bbb_fused": ["cs::cl::bbb<3, 2, 2, 1>", "cs::unpack_cl4"],
 }
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --steps 1 --warmup 1 (tools/profile_round.sh %s); raw, see tools/pmc_to_traffic.py" % tag,
-           "bytes_per_launch": stage}, open("profiles/stage_traffic.json", "w"), indent=1)
-print(json.dumps(stage, indent=1))
+import bench
+out = {"source": "rocprofv3 --pmc, one pass per counter group, python bench.py --steps 1 --warmup 1 (tools/profile_round.sh %s); "
+                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md (128-byte read "
+                 "requests are tallied at 64 bytes); raw and by-request-size figures alongside" % tag,
+       "csrc_digest": bench.csrc_digest(),
+       "bytes_per_launch": {}, "raw": {}, "by_request_size": {}}
+for st, ks in stages.items():
+    extra = T if st in ("backward", "backward_backward", "bbb_fused") else 0
+    out["bytes_per_launch"][st] = total(ks, "corrected") + extra
+    out["raw"][st] = total(ks, "raw") + extra
+    out["by_request_size"][st] = total(ks, "by_size") + extra
+json.dump(out, open(os.path.join(ROOT, "profiles", "stage_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
