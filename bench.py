@@ -144,7 +144,7 @@ def helmholtz_step(N, C, H, P, dev, steps=3):
     return e0.elapsed_time(e1) / steps
 
 
-def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10):
+def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None):
     """forward + the three backward stages on synthetic inputs of the given shape (any of BASELINE.json's configs or
     the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step)."""
     from cosinesampler_amd import multicell_offset, ops
@@ -155,13 +155,15 @@ def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10):
     oshape = (N, C) + (1,) * (dim - 1) + (P,)
     gOut = torch.randn(oshape, generator=g).to(dev)
     hO = torch.randn(oshape, generator=g).to(dev)
+    if stream_dtype is not None:     # the channel-major streams in float16 / bfloat16, read and written natively
+        gOut, hO = gOut.to(stream_dtype), hO.to(stream_dtype)
     cG = torch.randn(grid.shape, generator=g).to(dev)
     hG = torch.randn(grid.shape, generator=g).to(dev)
     off = multicell_offset(N, True, dev)
 
     def one():
         sc = ops.StepContext()
-        ops.forward(cells, grid, off, 0, True, kernel, True, ctx=sc)
+        ops.forward(cells, grid, off, 0, True, kernel, True, ctx=sc, out_dtype=stream_dtype)
         ops.backward(gOut, cells, grid, off, 0, True, True, kernel, True, ctx=sc)
         ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, kernel, True, ctx=sc)
         ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, kernel, True, ctx=sc)
@@ -357,6 +359,11 @@ def main():
             for key, what, dim_, n_, c_, size_, p_, kern_ in OTHER_SHAPES:   # the same four stages at other shapes
                 ms_o, s_o = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_)
                 line[key] = {"ms_per_step": ms_o, "Msamples_per_s": s_o / ms_o / 1e3, "what": what}
+            ms_h, s_h = stage_pipeline_ms(dev, 2, N, C, H, P, 0, stream_dtype=torch.bfloat16)
+            line["bf16_streams"] = {"ms_per_step": ms_h, "Msamples_per_s": s_h / ms_h / 1e3,
+                                    "what": "the headline step with output / grad_output / grad_grad_out / grad_out_ggout "
+                                            "in bfloat16 (CS_STREAM_BF16: native 16-bit stream I/O, fp32 arithmetic, "
+                                            "table and grid fp32); reported next to the fp32 headline, not instead of it"}
             ms = helmholtz_step(N, C, H, P, dev)
             line["pixel_helmholtz_autograd"] = {
                 "ms_per_step": ms, "Msamples_per_s": S / ms / 1e3,

@@ -27,12 +27,13 @@ _STAGES = {
     "backward_backward_backward": 8,
     "bbb_fused": 9,
 }
-EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_pack_bytes", "cs_pack_input",
+EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_streams_supported", "cs_pack_bytes", "cs_pack_input",
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
 ABI_VERSION = 7
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
+STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 
@@ -57,6 +58,8 @@ def load():
     lib.cs_error_string.argtypes = [_c_int]
     lib.cs_workspace_bytes.restype = _c_sz
     lib.cs_workspace_bytes.argtypes = [_c_int, _c_int] + [_c_i64] * 6 + [_c_int] * 3
+    lib.cs_half_streams_supported.restype = _c_int
+    lib.cs_half_streams_supported.argtypes = [_c_int] + [_c_i64] * 6
     lib.cs_pack_bytes.restype = _c_sz
     lib.cs_pack_bytes.argtypes = [_c_int] + [_c_i64] * 6
     lib.cs_pack_input.restype = _c_int

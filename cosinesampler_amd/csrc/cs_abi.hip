@@ -26,6 +26,7 @@ struct Problem {
     Flags f;
     int dim;
     int kernel;
+    int sdt;      // element type of the channel-major streams: 0 fp32, 1 half, 2 bfloat16 (CS_STREAM_*)
     hipStream_t stream;
     unsigned blocks;
 };
@@ -34,7 +35,9 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
                  int padding_mode, int align_corners, int kernel, int multicell, void *stream) {
     if (N < 0 || C < 0 || P < 0 || D < 1 || H < 1 || W < 1) return CS_ERR_INVALID;
     const int exact = (kernel & CS_KERNEL_EXACT_MIXED) ? 1 : 0;
-    kernel &= ~CS_KERNEL_EXACT_MIXED;
+    if ((kernel & CS_STREAM_F16) && (kernel & CS_STREAM_BF16)) return CS_ERR_INVALID;
+    pb.sdt = (kernel & CS_STREAM_F16) ? 1 : (kernel & CS_STREAM_BF16) ? 2 : 0;
+    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16);
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
     // node indices and sizes are kept in 32-bit registers; element offsets are 64-bit
     if (N > INT32_MAX || C > INT32_MAX || D > (1 << 28) || H > (1 << 28) || W > (1 << 28)) return CS_ERR_UNSUPPORTED;
@@ -137,12 +140,19 @@ int allow_lds(K kernel, size_t bytes) {
     return e == hipSuccess ? CS_OK : (int)e;
 }
 
-// kernel-enum dispatch: KERNEL is a template parameter so the unused derivative paths fold away
-#define CS_DISPATCH_KERNEL(kernel_enum, ...)                                  \
+// kernel-enum dispatch: KERNEL is a template parameter so the unused derivative paths fold away; ST is the element type
+// of the channel-major streams (`pb.sdt`, the fast paths only: kernels that do not take it are the same symbol thrice)
+#define CS_DISPATCH_KERNEL_(kernel_enum, ...)                                 \
     switch (kernel_enum) {                                                    \
         case CS_KERNEL_COSINE: { constexpr int KERNEL = cs::K_COSINE; __VA_ARGS__; } break;       \
         case CS_KERNEL_LINEAR: { constexpr int KERNEL = cs::K_LINEAR; __VA_ARGS__; } break;       \
         default:               { constexpr int KERNEL = cs::K_SMOOTHSTEP; __VA_ARGS__; } break;   \
+    }
+#define CS_DISPATCH_KERNEL(kernel_enum, ...)                                                              \
+    switch (pb.sdt) {                                                                                     \
+        case 1:  { using ST = cs::stream_f16; (void)sizeof(ST); CS_DISPATCH_KERNEL_(kernel_enum, __VA_ARGS__) } break;   \
+        case 2:  { using ST = cs::stream_bf16; (void)sizeof(ST); CS_DISPATCH_KERNEL_(kernel_enum, __VA_ARGS__) } break;  \
+        default: { using ST = float; (void)sizeof(ST); CS_DISPATCH_KERNEL_(kernel_enum, __VA_ARGS__) } break;             \
     }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,8 +479,8 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
-                                      pr.icl, grid, offset, output, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ, ST><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
+                                      pr.icl, grid, offset, (ST *)output, pb.d, pb.f))));
     return launch_status();
 }
 
@@ -483,8 +493,8 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
-                                          gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
+                                          (const ST *)gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
         return launch_status();
     }
     // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
@@ -492,8 +502,8 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
-                                      gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
+                                      (const ST *)gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     // a caller's plan outlives this call: when asked, leave the sorted copy of grad_output in it for later stages' walkers
@@ -529,8 +539,8 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     }
     const size_t shm = q_lds(tl::row1((int)cpad(pb.d.C)), 12);
 #define CS_TILED_BB(HAS_CI, ROWS)                                                                                      \
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, HAS_CI, ROWS><<<point_grid(pb), kBlock, shm, pb.stream>>>( \
-                                      cIcl, cG, pr.icl, grid, gOut, offset, fat, gGrid, ggOut, pb.d, pb.f))))
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, HAS_CI, ROWS, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>( \
+                                      cIcl, cG, pr.icl, grid, (const ST *)gOut, offset, fat, gGrid, (ST *)ggOut, pb.d, pb.f))))
     if (!gInput) { if (cIcl) { CS_TILED_BB(true, 0); } else { CS_TILED_BB(false, 0); } }
     else if (lean) { if (cIcl) { CS_TILED_BB(true, 2); } else { CS_TILED_BB(false, 2); } }
     else { if (cIcl) { CS_TILED_BB(true, 1); } else { CS_TILED_BB(false, 1); } }
@@ -557,9 +567,9 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     if (lean) {
         const size_t shm = q_lds(tl::row3((int)cpad(pb.d.C)), 0);
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
-            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, true>, shm);
-            if (!rc) tl::point_bbb<KERNEL, CQ, true, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                         pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f);
+            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, true, ST>, shm);
+            if (!rc) tl::point_bbb<KERNEL, CQ, true, true, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f);
         }));
         if (rc) return rc;
         rc = launch_status();
@@ -569,9 +579,9 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     if (hO) {
         const size_t shm = q_lds(tl::row2((int)cpad(pb.d.C)), 0);   // 80 KiB at 32 channels
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
-            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true>, shm);
-            if (!rc) tl::point_bbb<KERNEL, CQ, true><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                         pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f);
+            rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, false, ST>, shm);
+            if (!rc) tl::point_bbb<KERNEL, CQ, true, false, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>(
+                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f);
         }));
         if (rc) return rc;
         rc = launch_status();
@@ -579,8 +589,8 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<1, true>(pb, pr.plan, fat, gInput);
         return launch_tile_scatter<1>(pb, pr.plan, fat, gInput);
     } else {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
-                                          pr.icl, grid, gOut, cG, hG, hO, offset, fat, ggOut, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
+                                          pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);
@@ -704,8 +714,8 @@ int rcl_forward(const Problem &pb, const float *input, const float *grid, const 
     const float *icl;
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::forward<DIM, KERNEL, CQ><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                      icl, grid, offset, output, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::forward<DIM, KERNEL, CQ, ST><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                      icl, grid, offset, (ST *)output, pb.d, pb.f))));
     return launch_status();
 }
 
@@ -759,8 +769,8 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 0><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                          gOut, icl, grid, offset, grad_grid, nullptr, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 0, ST><<<pb.blocks, kBlock, 0, pb.stream>>>(
+                                          (const ST *)gOut, icl, grid, offset, grad_grid, nullptr, pb.d, pb.f))));
         return launch_status();
     }
     const size_t shm = rcl_lds<DIM>(pb.d.C, 0);
@@ -771,8 +781,8 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
         if (rc) return rc;
         rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                          gOut, icl, grid, offset, grad_grid, rows, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                          (const ST *)gOut, icl, grid, offset, grad_grid, rows, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return dense3_scatter<0>(pb, pl, rows, grad_input);
@@ -780,8 +790,8 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 1><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      gOut, icl, grid, offset, grad_grid, acc, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 1, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                      (const ST *)gOut, icl, grid, offset, grad_grid, acc, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     return rcl_finish(pb, acc, grad_input);
@@ -818,8 +828,8 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
     }
     const size_t shm = gInput ? rcl_lds<DIM>(pb.d.C, 1) : 0;
 #define CS_RCL_BB(HAS_CI, SCATTER)                                                                                   \
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, HAS_CI, SCATTER>  \
-                                      <<<pb.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, gOut, offset, gGrid, ggOut, acc, pb.d, pb.f))))
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, HAS_CI, SCATTER, ST>  \
+                                      <<<pb.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, (const ST *)gOut, offset, gGrid, (ST *)ggOut, acc, pb.d, pb.f))))
     if (cIcl && dense) { CS_RCL_BB(true, 2); }
     else if (cIcl && gInput) { CS_RCL_BB(true, 1); }
     else if (cIcl) { CS_RCL_BB(true, 0); }
@@ -849,8 +859,8 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
         if (rc) return rc;
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                          icl, grid, gOut, cG, hG, hO, offset, ggOut, rows, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                          icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, rows, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return dense3_scatter<2>(pb, pl, rows, gInput);
@@ -858,8 +868,8 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 1><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      icl, grid, gOut, cG, hG, hO, offset, ggOut, acc, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 1, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
+                                      icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, acc, pb.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     return rcl_finish(pb, acc, gInput);
@@ -921,6 +931,12 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
     }
     if (stage != CS_STAGE_FORWARD && rows_applies(N, C, P, vol)) return align256((size_t)N * C * vol * 4);
     return 0;
+}
+
+int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+    if (dim == 2) return tiled_applies(2, N, C, H, W, P) ? 1 : 0;
+    return (dim == 3 && rows_cl_applies(3, N, C, P, D * H * W)) ? 1 : 0;
 }
 
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
@@ -1012,6 +1028,7 @@ int cs2d_forward(const float *input, const float *grid, const float *offset, flo
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, offset, output)
     if (tiled) return tiled_forward(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;   // 16-bit streams: fast paths only (cs_half_streams_supported)
     return run_forward<2>(pb, table_, grid, offset, output);
 }
 
@@ -1025,6 +1042,7 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                               workspace_bytes, g_leave);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows && grad_input) {
         int rc = run_backward<2>(pb, grad_output, table_, grid, offset, nullptr, grad_grid);
         if (rc) return rc;
@@ -1047,6 +1065,7 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
     const bool exact_ci = tiled && pb.f.exact && grad_out_input;
     const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
+    if (pb.sdt && (!tiled || exact_ci)) return CS_ERR_UNSUPPORTED;
     if (tiled && !exact_ci)
         return tiled_bb(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                         grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
@@ -1073,6 +1092,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -1096,6 +1116,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows) {
         int rc = run_bbb<2>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);
@@ -1116,6 +1137,7 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
     CS_NEED(input, grid, offset, output)
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_forward<3>(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     return run_forward<3>(pb, table_, grid, offset, output);
 }
 
@@ -1129,6 +1151,7 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                                workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows && grad_input) {
         int rc = run_backward<3>(pb, grad_output, table_, grid, offset, nullptr, grad_grid);
         if (rc) return rc;
@@ -1150,6 +1173,7 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows) {
         int rc = run_bb<3>(pb, grad_out_input, grad_out_grid, table_, grid, grad_output, offset, nullptr, grad_grid,
                            grad_grad_out);
@@ -1173,6 +1197,7 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                           grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, nullptr,
                             grad_grad_out);
@@ -1195,6 +1220,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                           grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     if (rows) {
         int rc = run_bbb<3>(pb, table_, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                             nullptr, grad_grad_out);
@@ -1217,6 +1243,7 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
 
@@ -1231,6 +1258,7 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    if (pb.sdt) return CS_ERR_UNSUPPORTED;
     return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
 

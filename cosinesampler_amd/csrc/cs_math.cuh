@@ -25,6 +25,17 @@ enum { K_COSINE = 0, K_LINEAR = 1, K_SMOOTHSTEP = 2 };
 
 constexpr float kPi = 3.14159265358979323846f;
 
+// Element types of the channel-major STREAMS (output, grad_output, grad_grad_out, grad_out_ggout): fp32, IEEE half or
+// bfloat16 (include/cosine_sampler.h, CS_STREAM_F16 / CS_STREAM_BF16).  The reference dispatches half too (2d.cu:905)
+// and, like here, evaluates weights and sums in float whatever the tensor type (2d.cu:239-261, :430-431).  Everything
+// else -- table, grid and its cotangents, the input-shaped gradients -- stays fp32.
+typedef _Float16 stream_f16;
+typedef __bf16 stream_bf16;
+template <typename T>
+__device__ __forceinline__ float stream_load(const T *p) { return (float)__builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, float v) { __builtin_nontemporal_store((T)v, p); }
+
 struct Flags {
     int pad;
     int align;      // as given by the caller

@@ -18,19 +18,21 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 // the 4 channels of a quad of a channel-major stream; cv = how many of them exist (C = 1..3 runs zero-padded)
-__device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
+template <typename T>
+__device__ __forceinline__ float4 load_quad(const T *src, int64_t P, int cv) {
     float4 r;
-    r.x = cv > 0 ? __builtin_nontemporal_load(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
-    r.y = cv > 1 ? __builtin_nontemporal_load(src + P) : 0.0f;
-    r.z = cv > 2 ? __builtin_nontemporal_load(src + 2 * P) : 0.0f;
-    r.w = cv > 3 ? __builtin_nontemporal_load(src + 3 * P) : 0.0f;
+    r.x = cv > 0 ? stream_load(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
+    r.y = cv > 1 ? stream_load(src + P) : 0.0f;
+    r.z = cv > 2 ? stream_load(src + 2 * P) : 0.0f;
+    r.w = cv > 3 ? stream_load(src + 3 * P) : 0.0f;
     return r;
 }
-__device__ __forceinline__ void store_quad(float *dst, int64_t P, float4 o, int cv) {
-    if (cv > 0) __builtin_nontemporal_store(o.x, dst);
-    if (cv > 1) __builtin_nontemporal_store(o.y, dst + P);
-    if (cv > 2) __builtin_nontemporal_store(o.z, dst + 2 * P);
-    if (cv > 3) __builtin_nontemporal_store(o.w, dst + 3 * P);
+template <typename T>
+__device__ __forceinline__ void store_quad(T *dst, int64_t P, float4 o, int cv) {
+    if (cv > 0) stream_store(dst, o.x);
+    if (cv > 1) stream_store(dst + P, o.y);
+    if (cv > 2) stream_store(dst + 2 * P, o.z);
+    if (cv > 3) stream_store(dst + 3 * P, o.w);
 }
 
 // node rows of one channel quad; zero-padded nodes read row 0 and are masked
@@ -99,9 +101,9 @@ __device__ __forceinline__ void flush_records(const float *stage, float *__restr
     }
 }
 
-template <int DIM, int KERNEL, int CQ>
+template <int DIM, int KERNEL, int CQ, typename ST = float>
 __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, const float *__restrict__ grid,
-                                               const float *__restrict__ offset, float *__restrict__ out, Dims d,
+                                               const float *__restrict__ offset, ST *__restrict__ out, Dims d,
                                                Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
     Sample<DIM> sm;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     float W[NC];
     sm.weights(W);
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float *o = out + (int64_t)sm.n * d.C * d.P + sm.p;   // d.C: the caller's channel count (C is the padded one)
+    ST *o = out + (int64_t)sm.n * d.C * d.P + sm.p;   // d.C: the caller's channel count (C is the padded one)
     float4 v[CQ][NC];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     }
 }
 
-template <int DIM, int KERNEL, int CQ, int SCATTER>
-__global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, const float *__restrict__ icl,
+template <int DIM, int KERNEL, int CQ, int SCATTER, typename ST = float>
+__global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, const float *__restrict__ icl,
                                                 const float *__restrict__ grid, const float *__restrict__ offset,
                                                 float *__restrict__ grad_grid, float *__restrict__ acc_cl, Dims d,
                                                 Flags f) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
 #pragma unroll
     for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+    const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float4 v[CQ][NC], g[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
@@ -181,11 +183,11 @@ __global__ __launch_bounds__(256) void backward(const float *__restrict__ gOut, 
     }
 }
 
-template <int DIM, int KERNEL, int CQ, bool HAS_CI, int SCATTER>
+template <int DIM, int KERNEL, int CQ, bool HAS_CI, int SCATTER, typename ST = float>
 __global__ __launch_bounds__(256) void backward_backward(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                          const float *__restrict__ icl, const float *__restrict__ grid,
-                                                         const float *__restrict__ gOut, const float *__restrict__ offset,
-                                                         float *__restrict__ gGrid, float *__restrict__ ggOut,
+                                                         const ST *__restrict__ gOut, const float *__restrict__ offset,
+                                                         float *__restrict__ gGrid, ST *__restrict__ ggOut,
                                                          float *__restrict__ acc_cl, Dims d, Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
     constexpr bool FULL = (DIM == 3);   // mixed second derivatives + gOutInput -> grad_grid (3d.cu:758-771, :837-839)
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
-    const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 g = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
@@ -275,11 +277,11 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     }
 }
 
-template <int DIM, int KERNEL, int CQ, int SCATTER>
+template <int DIM, int KERNEL, int CQ, int SCATTER, typename ST = float>
 __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const float *__restrict__ grid,
-                                           const float *__restrict__ gOut, const float *__restrict__ cG,
-                                           const float *__restrict__ hG, const float *__restrict__ hO,
-                                           const float *__restrict__ offset, float *__restrict__ ggOut,
+                                           const ST *__restrict__ gOut, const float *__restrict__ cG,
+                                           const float *__restrict__ hG, const ST *__restrict__ hO,
+                                           const float *__restrict__ offset, ST *__restrict__ ggOut,
                                            float *__restrict__ acc_cl, Dims d, Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
     using R = Rec<DIM, CQ, 2>;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
         }
     }
     if (SCATTER) {   // cotangent streams and coefficients of the scatter: E_a * gOut + D_a * hO
-        const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+        const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             *reinterpret_cast<float4 *>(rec + 4 * q) = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
         }
     }
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     float4 v[CQ][NC];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);

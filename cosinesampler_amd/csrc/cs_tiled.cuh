@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
 __device__ __forceinline__ void st_stream_wt(float *p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void st_stream_wt(T *p, float v) { stream_store(p, v); }   // 16-bit streams: nontemporal
+template <typename T>
+__device__ __forceinline__ float ld_stream(const T *p) { return stream_load(p); }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
@@ -357,7 +360,8 @@ __device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs,
         if (qs.node[a] == NO_NODE) v[a] = zero4();
 }
 // the 4 channels 4q..4q+3 of a channel-major stream; channels >= cv do not exist (C < 4 runs zero-padded as CQ = 1)
-__device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv) {
+template <typename T>
+__device__ __forceinline__ float4 load_quad(const T *src, int64_t P, int cv) {
     float4 r;
     r.x = cv > 0 ? ld_stream(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
     r.y = cv > 1 ? ld_stream(src + P) : 0.0f;
@@ -365,9 +369,9 @@ __device__ __forceinline__ float4 load_quad(const float *src, int64_t P, int cv)
     r.w = cv > 3 ? ld_stream(src + 3 * P) : 0.0f;
     return r;
 }
-template <int KERNEL, int CQ>
+template <int KERNEL, int CQ, typename ST = float>
 __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ icl, const float *__restrict__ grid,
-                                                     const float *__restrict__ offset, float *__restrict__ out,
+                                                     const float *__restrict__ offset, ST *__restrict__ out,
                                                      Dims d, Flags f) {
     extern __shared__ float lds[];
     constexpr int C = 4 * CQ;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     __syncthreads();
     const int n = blockIdx.y;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
-    float *obase = out + (int64_t)n * d.C * d.P;   // d.C: the caller's channel count (template C is the padded one)
+    ST *obase = out + (int64_t)n * d.C * d.P;   // d.C: the caller's channel count (template C is the padded one)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
@@ -446,16 +450,16 @@ struct Sample2 {
     }
 };
 
-template <int CQ>
-__device__ __forceinline__ void load_stream(const float *src, int64_t P, float4 (&g)[CQ], int C) {
+template <int CQ, typename T>
+__device__ __forceinline__ void load_stream(const T *src, int64_t P, float4 (&g)[CQ], int C) {
 #pragma unroll
     for (int q = 0; q < CQ; ++q) g[q] = load_quad(src + (int64_t)(4 * q) * P, P, C - 4 * q);
 }
-template <int CQ>
-__device__ __forceinline__ void store_stream(float *dst, int64_t P, const float4 (&o)[CQ], int C) {
+template <int CQ, typename T>
+__device__ __forceinline__ void store_stream(T *dst, int64_t P, const float4 (&o)[CQ], int C) {
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
-        float *p = dst + (int64_t)(4 * q) * P;
+        T *p = dst + (int64_t)(4 * q) * P;
         const int cv = C - 4 * q;
         if (cv > 0) st_stream_wt(p, o[q].x);
         if (cv > 1) st_stream_wt(p + P, o[q].y);
@@ -530,20 +534,20 @@ __device__ __forceinline__ float q_reduce(float x) {
     if (CQ >= 8) x += __shfl_xor(x, 4);
     return x;
 }
-template <int CQ>
-__device__ __forceinline__ void q_store_rows(const float *stage, int stride, float *dst, int64_t P, bool live, int C) {
+template <int CQ, typename T>
+__device__ __forceinline__ void q_store_rows(const float *stage, int stride, T *dst, int64_t P, bool live, int C) {
     if (!live) return;
     const float *row = stage + (threadIdx.x & 63) * stride;
     float4 o[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) o[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
-    store_stream<CQ>(dst, P, o, C);
+    store_stream<CQ, T>(dst, P, o, C);
 }
 
 // first backward.  LDS stage row = the fat row [g | W0..W3] (flushed when WANT_ROWS: grad_input is wanted);
 // `co` = [4][64]: wx0 wx1 wy0 wy1 for the grad_grid dot products of phase 2.
-template <int KERNEL, int CQ, bool WANT_ROWS>
-__global__ __launch_bounds__(256) void point_backward(const float *__restrict__ gOut, const float *__restrict__ icl,
+template <int KERNEL, int CQ, bool WANT_ROWS, typename ST = float>
+__global__ __launch_bounds__(256) void point_backward(const ST *__restrict__ gOut, const float *__restrict__ icl,
                                                       const float *__restrict__ grid, const float *__restrict__ offset,
                                                       float *__restrict__ fat, float *__restrict__ grad_grid,
                                                       Dims d, Flags f) {
@@ -598,12 +602,12 @@ __global__ __launch_bounds__(256) void point_backward(const float *__restrict__ 
 // sets Sx, Sy (and W for HAS_CI) live in a second record block `co`: [12][64]
 // ROWS: 0 nothing for the scatter (grad_input not wanted), 1 the fat rows [gOut | D], 2 the 16-byte D record alone
 // (p-ordered, `fat` = S float4): the walkers then take gOut from the sorted copy an earlier stage left (Plan::Gs)
-template <int KERNEL, int CQ, bool HAS_CI, int ROWS>
+template <int KERNEL, int CQ, bool HAS_CI, int ROWS, typename ST = float>
 __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                   const float *__restrict__ icl, const float *__restrict__ grid,
-                                                  const float *__restrict__ gOut, const float *__restrict__ offset,
+                                                  const ST *__restrict__ gOut, const float *__restrict__ offset,
                                                   float *__restrict__ fat, float *__restrict__ gGrid,
-                                                  float *__restrict__ ggOut, Dims d, Flags f) {
+                                                  ST *__restrict__ ggOut, Dims d, Flags f) {
     constexpr int C = 4 * CQ, STRIDE = row1(C), CO = 12 * 64;
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * STRIDE + QREC + CO);
@@ -685,12 +689,12 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
 // LEAN (with TWO): [hO | E | D] -- grad_output is neither read nor written again, the walkers stream its sorted copy
 // (padding these rows to whole 128-byte lines was measured and dropped: point kernel +0.09 ms, walkers -0.02 ms)
 __host__ __device__ constexpr int row3(int C) { return C + 8; }
-template <int KERNEL, int CQ, bool TWO, bool LEAN = false>
+template <int KERNEL, int CQ, bool TWO, bool LEAN = false, typename ST = float>
 __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, const float *__restrict__ grid,
-                                                   const float *__restrict__ gOut, const float *__restrict__ cG,
-                                                   const float *__restrict__ hG, const float *__restrict__ hO,
+                                                   const ST *__restrict__ gOut, const float *__restrict__ cG,
+                                                   const float *__restrict__ hG, const ST *__restrict__ hO,
                                                    const float *__restrict__ offset, float *__restrict__ fat,
-                                                   float *__restrict__ ggOut, Dims d, Flags f) {
+                                                   ST *__restrict__ ggOut, Dims d, Flags f) {
     static_assert(!LEAN || TWO, "the lean rows carry grad_out_ggout");
     constexpr int C = 4 * CQ, STRIDE = LEAN ? row3(C) : TWO ? row2(C) : row1(C), EOFF = LEAN ? C : TWO ? 2 * C : C;
     extern __shared__ float lds[];

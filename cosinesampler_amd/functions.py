@@ -111,6 +111,17 @@ def _as(t, like):
     return t if t is None or t.dtype == like.dtype else t.to(like.dtype)
 
 
+_HALVES = (torch.float16, torch.bfloat16)
+
+
+def _stream(t, step):
+    """A channel-major stream (grad_output, grad_out_ggout) as the kernels take it: float16 / bfloat16 stay as they are
+    where the problem runs on a path with native 16-bit streams (step.half_ok), everything else becomes fp32."""
+    if t is not None and t.dtype in _HALVES and step.half_ok:
+        return t
+    return _f32(t)
+
+
 def _engine_wants(ctx, i):
     """Will the running backward pass use the gradient this node returns for its i-th forward input?
     `ctx.needs_input_grad` only says that the input requires grad; under
@@ -143,8 +154,12 @@ def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multice
     # channels-last input copy + point plan, shared by this call's backward chain; which grad_output's sorted copy is
     # worth leaving in the plan is decided from the nodes that announce themselves (StepContext.expect)
     step = ops.StepContext(reuse_grad_output=False)
-    output = _as(ops.forward(_f32(input), _f32(grid), offset, cfg.pad, cfg.align_corners, cfg.kernel,
-                             cfg.multicell, ctx=step), input)
+    x32, g32 = _f32(input), _f32(grid)
+    # float16 / bfloat16 callers: the table and the grid (small) are converted, the big channel-major tensors are read and
+    # written in the caller's type by the kernels themselves wherever a fast path applies
+    step.half_ok = input.dtype in _HALVES and ops.half_streams_ok(x32, g32)
+    output = _as(ops.forward(x32, g32, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step,
+                             out_dtype=input.dtype if step.half_ok else None), input)
     ctx.save_for_backward(input, grid)
     ctx.offset = offset
     ctx.cfg = cfg
@@ -158,7 +173,7 @@ def _backward(ctx, grad_out):
         return None, None, None, None, None, None
     grad_out = ops.keep_expanded(grad_out)
     if torch.is_grad_enabled():        # create_graph: the node made here may run a scatter stage on grad_out later
-        ctx.step.expect(_f32(grad_out))
+        ctx.step.expect(_stream(grad_out, ctx.step))
     d_input, d_grid = _SamplerBackward.apply(input, grid, grad_out, ctx.offset, ctx.cfg,
                                              _engine_wants(ctx, 0), ctx.step)
     return d_input, d_grid, None, None, None, None
@@ -204,7 +219,7 @@ class _SamplerBackward(Function):
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
-        grad_input, grad_grid = ops.backward(_f32(gOut), _f32(input), _f32(grid), offset, cfg.pad,
+        grad_input, grad_grid = ops.backward(_stream(gOut, step), _f32(input), _f32(grid), offset, cfg.pad,
                                              cfg.align_corners, bool(input_requires_grad), cfg.kernel, cfg.multicell,
                                              ctx=step)
         ctx.save_for_backward(input, grid, gOut)
@@ -216,7 +231,7 @@ class _SamplerBackward(Function):
         if gOutInput is None and gOutGrid is None:
             return None, None, None, None, None, None, None
         if torch.is_grad_enabled():    # create_graph: a third backward through the node made here scatters with gOut again
-            ctx.step.expect(_f32(gOut))
+            ctx.step.expect(_stream(gOut, ctx.step))
         gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
                                                               ctx.offset, ctx.cfg, ctx.step, _engine_wants(ctx, 0))
         return gInput, gGrid, ggOut, None, None, None, None
@@ -233,7 +248,7 @@ class _SamplerBackwardBackward(Function):
         ctx.cfg = cfg
         ctx.step = step
         gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
-                                                     _f32(gOut), offset, cfg.pad, cfg.align_corners,
+                                                     _stream(gOut, step), offset, cfg.pad, cfg.align_corners,
                                                      gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step,
                                                      want_grad_input=bool(want_grad_input))
         gInput, gGrid, ggOut = _as(gInput, input), _as(gGrid, grid), _as(ggOut, gOut)
@@ -255,13 +270,17 @@ class _SamplerBackwardBackward(Function):
         if gOutgGrid is None and gOutggOut is None:
             return None, None, None, None, None, None, None, None, None
         cfg = ctx.cfg
-        hG, hO = _f32(_c(gOutgGrid)), _f32(ops.keep_expanded(gOutggOut))
-        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
+        hG, hO = _f32(_c(gOutgGrid)), ops.keep_expanded(gOutggOut)
+        gO = _stream(gOut, ctx.step)
+        hO = _stream(hO, ctx.step)
+        if hO is not None and hO.dtype != gO.dtype:      # mixed types: the streams of one call share one
+            gO, hO = _f32(gO), _f32(hO)
+        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), gO, _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
                                       cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
         # '+mixed' kernels also return the gradient w.r.t. grid here (u_xxx, u_xxy): the reference has none
         # (modules_2d.py:111).  Terms through gOutInput are not propagated, as everywhere at this level.
         gGrid3 = None
         if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and _engine_wants(ctx, 1):
-            gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
+            gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, _f32(hO), ctx.offset, cfg.pad,
                                       cfg.align_corners, cfg.kernel, cfg.multicell), grid)
         return _as(gInput, input), gGrid3, _as(ggOut, gOut), None, None, None, None, None, None

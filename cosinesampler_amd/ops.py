@@ -32,14 +32,27 @@ def _check(t, name, allow_none=False):
         raise RuntimeError("%s must be float32 (got %s): only the fp32 path is built" % (name, t.dtype))
 
 
+STREAM_DTYPES = {torch.float32: 0, torch.float16: _lib.STREAM_F16, torch.bfloat16: _lib.STREAM_BF16}
+
+
+def half_streams_ok(input, grid):
+    """Can the channel-major streams of this problem be float16 / bfloat16 natively (CS_STREAM_F16 / CS_STREAM_BF16)?
+    Only the fast paths take them; elsewhere the caller converts."""
+    if not (input.is_cuda and grid.is_cuda):
+        return False
+    dim, shape, P = _problem(input, grid)
+    D = shape[2] if dim == 3 else 1
+    return bool(_lib.load().cs_half_streams_supported(dim, shape[0], shape[1], D, shape[-2], shape[-1], P))
+
+
 def _check_stream(t, name):
-    """A channel-major cotangent (N,C,[Do,]Ho,Wo): contiguous, or -- beyond the reference, which insists on
-    contiguous (2d.cpp:5) -- expanded along n (stride 0) over one contiguous (C,[Do,]Ho,Wo) block, which is what
-    the backward of PIXEL's `features.sum(0)` hands over.  -> the n-stride in elements."""
+    """A channel-major stream (N,C,[Do,]Ho,Wo), fp32 / float16 / bfloat16: contiguous, or -- beyond the reference,
+    which insists on contiguous (2d.cpp:5) -- expanded along n (stride 0) over one contiguous (C,[Do,]Ho,Wo) block, which
+    is what the backward of PIXEL's `features.sum(0)` hands over.  -> the n-stride in elements."""
     if t is None or not t.is_cuda:
         raise RuntimeError("%s must be a CUDA tensor" % name)
-    if t.dtype != torch.float32:
-        raise RuntimeError("%s must be float32 (got %s): only the fp32 path is built" % (name, t.dtype))
+    if t.dtype not in STREAM_DTYPES:
+        raise RuntimeError("%s must be float32, float16 or bfloat16 (got %s)" % (name, t.dtype))
     if t.is_contiguous():
         return t[0].numel() if t.shape[0] else 0
     if t.dim() >= 2 and t.stride(0) == 0 and t[0].is_contiguous():
@@ -118,6 +131,7 @@ class StepContext(object):
         # grad_outputs (a Helmholtz step: five scatter stages, four different tensors), so a copy is left only for a
         # tensor that `expect()` has announced at least twice.
         self.reuse_grad_output = reuse_grad_output
+        self.half_ok = False             # set by the autograd layer: 16-bit streams go to the kernels as they are
         self._expected = {}
         self._sorted_go = None
 
@@ -172,7 +186,7 @@ _force_epoch = 0
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None):
-    if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
+    if not isinstance(kernel, int) or (kernel & ~(EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16)) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
                         "got %r" % (kernel,))
@@ -224,10 +238,27 @@ def out_shape(input, grid):
     return tuple(input.shape[:2]) + tuple(grid.shape[1:-1])
 
 
-def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
+def _stream_kernel(kernel, *streams):
+    """kernel enum | the stream-dtype flag; the streams of one call share one element type."""
+    dts = {t.dtype for t in streams if t is not None}
+    if len(dts) > 1:
+        raise RuntimeError("the channel-major tensors of one call must share a dtype, got %s" % sorted(map(str, dts)))
+    dt = dts.pop() if dts else torch.float32
+    if not isinstance(kernel, int):
+        return kernel, dt           # rejected with a TypeError by _call, as before
+    return kernel | STREAM_DTYPES[dt], dt
+
+
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None, out_dtype=None):
+    """out_dtype (not in the reference's signature): torch.float16 / torch.bfloat16 to have `output` written in that
+    type by the kernel (fast paths only: half_streams_ok); default fp32."""
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
-    output = torch.empty(out_shape(input, grid), dtype=input.dtype, device=input.device)
+    out_dtype = out_dtype or input.dtype
+    if out_dtype not in STREAM_DTYPES:
+        raise RuntimeError("output dtype must be float32, float16 or bfloat16, got %s" % out_dtype)
+    output = torch.empty(out_shape(input, grid), dtype=out_dtype, device=input.device)
+    kernel, _ = _stream_kernel(kernel, output)
     _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P,
           padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset)
     return output
@@ -240,6 +271,7 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+    kernel, _ = _stream_kernel(kernel, grad_output)
     grad_input = torch.empty_like(input) if input_requires_grad else None
     grad_grid = torch.empty_like(grid)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
@@ -263,6 +295,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         grad_out_input = None
     if grad_out_grid is not None:
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
+    kernel, _ = _stream_kernel(kernel, grad_output)
     grad_input = torch.empty_like(input) if want_grad_input else None
     grad_grid = torch.empty_like(grid)
     grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
@@ -283,6 +316,7 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     _same(grad_out_ggrid, grid.shape, "grad_out_ggrid", input.device)
+    kernel, _ = _stream_kernel(kernel, grad_output)
     grad_input = torch.empty_like(input)
     grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("backward_backward_backward", dim,
@@ -307,6 +341,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
     ho_ns = None
     if grad_out_ggout is not None:
         ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
+    kernel, _ = _stream_kernel(kernel, grad_output, grad_out_ggout)
     grad_input = torch.empty_like(input)
     grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("bbb_fused", dim,

@@ -11,7 +11,8 @@
  *
  * Conventions
  *   - All tensors are contiguous fp32 in device memory (the reference's CHECK_CUDA /
- *     CHECK_CONTIGUOUS, 2d.cpp:4-6).  fp16/fp64 are not built yet: return CS_ERR_UNSUPPORTED.
+ *     CHECK_CONTIGUOUS, 2d.cpp:4-6); the channel-major streams may be half / bfloat16 instead (CS_STREAM_F16 /
+ *     CS_STREAM_BF16).  fp64 is not built: the Python layer converts.
  *   - 2D: input (N,C,H,W), grid (N,Ho,Wo,2), out/gOut (N,C,Ho,Wo);  P = Ho*Wo.
  *     3D: input (N,C,D,H,W), grid (N,Do,Ho,Wo,3), out/gOut (N,C,Do,Ho,Wo);  P = Do*Ho*Wo.
  *     grid[...,0] addresses W, [...,1] H, [...,2] D, each in [-1,1].
@@ -58,6 +59,14 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * 3d.cu:1008-1010).  With it u_xy and d(u_xy)/d(input) obtained through autograd are the exact derivatives of the
  * interpolant; without it (default) results are the reference's. */
 #define CS_KERNEL_EXACT_MIXED 0x100
+/* OR-ed into `kernel` (the reference dispatches half too, 2d.cu:905, :948, :1009, :1076): the channel-major STREAMS --
+ * output, grad_output, grad_grad_out, grad_out_ggout, the tensors of 4*N*C*P bytes each -- hold IEEE half / bfloat16
+ * instead of fp32; their pointers are then `_Float16*` / `__bf16*` passed through the `float*` parameters.  Weights,
+ * sums and every other tensor (input, grid and its cotangents, the input-shaped gradients) stay fp32, as the reference
+ * evaluates its weights in float whatever the dispatch type (2d.cu:239-261).  Native on the fast paths only
+ * (cs_half_streams_supported); elsewhere the calls return CS_ERR_UNSUPPORTED and the caller converts. */
+#define CS_STREAM_F16 0x1000
+#define CS_STREAM_BF16 0x2000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
 /* OR-ed into the stage id: the call will pass grad_input == NULL (first / second backward only) -- nothing is
@@ -96,6 +105,9 @@ const char *cs_error_string(int code);
  * backward_backward call will carry a grad_out_input (it needs its own channels-last copy). */
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI);
+
+/* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
+int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 
 /* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C rounded up to a multiple of 4 (the extra
  * channels are zero: 2D tables with 1..3 channels run as one float4 quad).  Returns the byte size of the copy / makes

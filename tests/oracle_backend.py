@@ -10,7 +10,7 @@ def _f(t):
     return None if t is None else t.contiguous()
 
 
-def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
+def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None, out_dtype=None):
     if kernel not in (0, 1, 2):
         raise TypeError("kernel enum")
     return cs_oracle.forward(_f(input), _f(grid), offset, padding_mode, align_corners, kernel, multicell)

@@ -401,21 +401,83 @@ def test_reference_test_scripts_at_their_own_shapes(d):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float16, torch.bfloat16])
 def test_other_float_dtypes_on_gpu(dtype):
-    """double / half / bfloat16 tensors are converted at the autograd boundary (fp32 kernels)."""
+    """double tensors are converted at the autograd boundary; half / bfloat16 tensors too on the direct path (a problem
+    this small), with fp32 kernels in between -- values checked against the fp32 op on the same (rounded) numbers."""
     torch.manual_seed(9)
-    cells32 = torch.rand(3, 4, 12, 12, device=DEV)
-    grid32 = torch.rand(3, 1, 500, 2, device=DEV) * 2 - 1
+    cells32 = torch.rand(3, 4, 12, 12, device=DEV).to(dtype).float()      # representable in `dtype`
+    grid32 = (torch.rand(3, 1, 500, 2, device=DEV) * 2 - 1).to(dtype).float()
     ref = CosineSampler2d.apply(cells32, grid32, "zeros", True, "cosine", True)
     cells = cells32.to(dtype).requires_grad_(True)
     grid = grid32.to(dtype).requires_grad_(True)
     out = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
     assert out.dtype == dtype
-    if dtype == torch.float64:
-        assert rel_err(out, ref) <= 1e-6
+    eps = {torch.float64: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert rel_err(out, ref) <= eps
     gI, gG = torch.autograd.grad(out.sum(), (cells, grid), create_graph=True)
     assert gI.dtype == dtype and gG.dtype == dtype and torch.isfinite(gI.float()).all()
     (gc,) = torch.autograd.grad(gG[..., 1].sum(), cells)
     assert gc.dtype == dtype and gc.shape == cells.shape
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("d,C", [(2, 16), (2, 6), (3, 8)])
+def test_native_half_streams(dtype, d, C):
+    """float16 / bfloat16 tensors on the fast paths: the channel-major streams (output, grad_output, grad_grad_out,
+    grad_out_ggout) are read and written in that type by the kernels (CS_STREAM_F16 / CS_STREAM_BF16; the reference
+    dispatches half too, 2d.cu:905, :948, :1009, :1076), fp32 arithmetic in between.  Every stage is compared with the
+    fp32 op on the same numbers: the inputs are representable in `dtype`, so results differ by the rounding of the
+    16-bit OUTPUTS only (fp32 outputs -- grad_grid, the input-shaped gradients -- agree to fp32 accuracy)."""
+    eps = 1e-3 if dtype == torch.float16 else 8e-3
+    N, P = 2, 40000
+    sp = (40, 33) if d == 2 else (9, 11, 7)
+    t = _case(d, N, C, sp, P, seed=5150 + C, spread=1.1)
+    off = offsets(N, True).to(DEV)
+    inp, grid, cG, hG = (_g(t[k]) for k in ("inp", "grid", "cG", "hG"))
+    gO16, hO16 = _g(t["gOut"]).to(dtype), _g(t["hO"]).to(dtype)
+    gO32, hO32 = gO16.float(), hO16.float()
+    assert ops.half_streams_ok(inp, grid)
+    ops.force_path(2)
+    try:
+        for shared in (False, True):
+            s16 = ops.StepContext() if shared else None
+            s32 = ops.StepContext() if shared else None
+            out16 = ops.forward(inp, grid, off, 0, True, 0, True, ctx=s16, out_dtype=dtype)
+            out32 = ops.forward(inp, grid, off, 0, True, 0, True, ctx=s32)
+            assert out16.dtype == dtype and rel_err(out16, out32) <= eps
+            gI16, gG16 = ops.backward(gO16, inp, grid, off, 0, True, True, 0, True, ctx=s16)
+            gI32, gG32 = ops.backward(gO32, inp, grid, off, 0, True, True, 0, True, ctx=s32)
+            assert gI16.dtype == torch.float32
+            assert_close(gI16, gI32, "half streams: grad_input")
+            assert_close(gG16, gG32, "half streams: grad_grid")
+            b16 = ops.backward_backward(None, cG, inp, grid, gO16, off, 0, True, False, 0, True, ctx=s16)
+            b32 = ops.backward_backward(None, cG, inp, grid, gO32, off, 0, True, False, 0, True, ctx=s32)
+            assert_close(b16[0], b32[0], "half streams: second-backward grad_input")
+            assert_close(b16[1], b32[1], "half streams: second-backward grad_grid")
+            assert b16[2].dtype == dtype and rel_err(b16[2], b32[2]) <= eps
+            f16 = ops.bbb_fused(inp, grid, gO16, cG, hG, hO16, off, 0, True, 0, True, ctx=s16)
+            f32 = ops.bbb_fused(inp, grid, gO32, cG, hG, hO32, off, 0, True, 0, True, ctx=s32)
+            assert_close(f16[0], f32[0], "half streams: third-backward grad_input")
+            assert f16[1].dtype == dtype and rel_err(f16[1], f32[1]) <= eps
+            k16 = ops.backward_backward_backward(inp, grid, gO16, cG, hG, off, 0, True, True, 0, True, ctx=s16)
+            k32 = ops.backward_backward_backward(inp, grid, gO32, cG, hG, off, 0, True, True, 0, True, ctx=s32)
+            assert_close(k16[0], k32[0], "half streams: K4 grad_input")
+            assert rel_err(k16[1], k32[1]) <= eps
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    # and through the autograd layer: half tensors in, half tensors out, no conversion of the big tensors
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    cells_h = inp.to(dtype).requires_grad_(True)
+    ops.force_path(2)
+    try:
+        out = Fn.apply(cells_h, grid.to(dtype), "zeros", True, "cosine", True)
+        ref = Fn.apply(cells_h.float(), grid.to(dtype).float(), "zeros", True, "cosine", True)
+        assert out.dtype == dtype and rel_err(out, ref) <= eps
+        (gc,) = torch.autograd.grad((out.float() * gO32).sum(), cells_h)
+        (gr,) = torch.autograd.grad((ref * gO32).sum(), cells_h)
+        assert gc.dtype == dtype and rel_err(gc, gr) <= eps
+    finally:
+        ops.force_path(0)
 
 
 def test_step_context_follows_in_place_updates():
