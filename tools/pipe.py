@@ -16,12 +16,15 @@ grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
 gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
 off = multicell_offset(N, True, dev)
+SD = {"": None, "bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("CS_STREAM", "")]
+if SD is not None:
+    gOut, hO = gOut.to(SD), hO.to(SD)
 if os.environ.get("CS_FORCE"):
     ops.force_path(int(os.environ["CS_FORCE"]))
 extra = os.environ.get("CS_EXTRA", "1") == "1"
 for step in range(int(os.environ.get("CS_STEPS", "5"))):
     sc = ops.StepContext()
-    ops.forward(cells, grid, off, 0, True, 0, True, ctx=sc)
+    ops.forward(cells, grid, off, 0, True, 0, True, ctx=sc, out_dtype=SD)
     ops.backward(gOut, cells, grid, off, 0, True, True, 0, True, ctx=sc)
     if extra:
         ops.backward(gOut, cells, grid, off, 0, True, False, 0, True, ctx=sc)

@@ -11,7 +11,7 @@ import csv,sys
 tot=0
 for r in csv.DictReader(open(sys.argv[1])):
     n=r["Name"]
-    if "cs::" in n or "zero_fill" in n:
+    if "cs::" in n or "zero_fill" in n or "_ZN2cs" in n:
         print("  %-64s calls %3s avg %8.1f us" % (n.split("(")[0][-64:], r["Calls"], float(r["AverageNs"])/1e3))
 PY
 done
