@@ -60,6 +60,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
     pb.f.exact = exact;
+    pb.f.pair16 = 0;
     pb.stream = (hipStream_t)stream;
     pb.blocks = (unsigned)((S + kBlock - 1) / kBlock);
     return CS_OK;
@@ -894,6 +895,13 @@ int bbb_grid_impl(Problem &pb, const float *input, const float *grid, const floa
     return launch_status();
 }
 
+// 16-bit streams move as dwords shared by lane pairs (cs_tiled.cuh ld_pair16) when every channel row starts on a dword
+void pair_streams(Problem &pb, std::initializer_list<const void *> streams) {
+    bool ok = pb.sdt != 0 && pb.d.P % 2 == 0 && pb.d.go_ns % 2 == 0 && pb.d.ho_ns % 2 == 0;
+    for (const void *q : streams) ok = ok && (reinterpret_cast<uintptr_t>(q) & 3) == 0;
+    pb.f.pair16 = ok ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1027,6 +1035,7 @@ int cs2d_forward(const float *input, const float *grid, const float *offset, flo
                  const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, offset, output)
+    pair_streams(pb, {output});
     if (tiled) return tiled_forward(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     if (pb.sdt) return CS_ERR_UNSUPPORTED;   // 16-bit streams: fast paths only (cs_half_streams_supported)
     return run_forward<2>(pb, table_, grid, offset, output);
@@ -1039,6 +1048,7 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    pair_streams(pb, {grad_output});
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                               workspace_bytes, g_leave);
@@ -1063,6 +1073,7 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
     // exact + grad_out_input: the grad_out_input -> grad_grid term is only in the direct kernel (run_bb)
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
+    pair_streams(pb, {grad_output, grad_grad_out});
     const bool exact_ci = tiled && pb.f.exact && grad_out_input;
     const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
     if (pb.sdt && (!tiled || exact_ci)) return CS_ERR_UNSUPPORTED;
@@ -1089,6 +1100,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    pair_streams(pb, {grad_output, grad_grad_out});
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);
@@ -1113,6 +1125,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    pair_streams(pb, {grad_output, grad_grad_out, grad_out_ggout});
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                          grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes, g_sorted, g_leave);

@@ -41,6 +41,7 @@ struct Flags {
     int align;      // as given by the caller
     int multicell;
     int exact;      // CS_KERNEL_EXACT_MIXED: keep the mixed second derivatives the reference drops (include/cosine_sampler.h)
+    int pair16;     // 16-bit streams whose rows are 4-byte aligned with P even: lane pairs move whole dwords (cs_tiled.cuh)
 };
 
 // k, k', k'' at t in [0,1] (2d.cu:239-261).  ORDER = highest derivative wanted.

@@ -21,6 +21,14 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 template <typename T>
 __device__ __forceinline__ float4 load_quad(const T *src, int64_t P, int cv) {
     float4 r;
+    if constexpr (sizeof(T) == 2) {   // 16-bit: the four loads are issued before the first conversion -- behind a branch
+        if (cv <= 0) return zero4();  // each one would be waited for on its own (cs_tiled.cuh StreamRegs)
+        const int last = cv > 3 ? 3 : cv - 1;
+        T t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __builtin_nontemporal_load(src + (int64_t)(k < last ? k : last) * P);
+        return make_float4((float)t[0], cv > 1 ? (float)t[1] : 0.0f, cv > 2 ? (float)t[2] : 0.0f, cv > 3 ? (float)t[3] : 0.0f);
+    }
     r.x = cv > 0 ? stream_load(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
     r.y = cv > 1 ? stream_load(src + P) : 0.0f;
     r.z = cv > 2 ? stream_load(src + 2 * P) : 0.0f;

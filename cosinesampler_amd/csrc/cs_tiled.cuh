@@ -285,6 +285,23 @@ __device__ __forceinline__ void st_stream_wt(T *p, float v) { stream_store(p, v)
 template <typename T>
 __device__ __forceinline__ float ld_stream(const T *p) { return stream_load(p); }
 
+// ---- 16-bit streams (float16 / bfloat16 elements, fp32 arithmetic) --------------------------------------------
+// When the channel rows are dword aligned and P is even (Flags::pair16) they move two samples per dword, straight
+// between HBM and the wave's LDS rows (StreamRegs / store_rows16 below); otherwise element by element.
+// the wave's first sample and how many of its 64 exist
+__device__ __forceinline__ int64_t wave_p0() { return (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); }
+__device__ __forceinline__ int wave_nlive(int64_t P) {
+    const int64_t r = P - wave_p0();
+    return r <= 0 ? 0 : (r > 64 ? 64 : (int)r);
+}
+template <typename T>
+__device__ __forceinline__ float half_of(uint32_t w, bool hi) {
+    const uint16_t b = hi ? (uint16_t)(w >> 16) : (uint16_t)w;
+    return (float)__builtin_bit_cast(T, b);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t bits16(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (T)v); }
+
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
     return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
@@ -363,6 +380,18 @@ __device__ __forceinline__ void gather4(const float4 *tab, const QuadSample &qs,
 template <typename T>
 __device__ __forceinline__ float4 load_quad(const T *src, int64_t P, int cv) {
     float4 r;
+    if constexpr (sizeof(T) == 2) {   // all four loads in flight before the first conversion (see StreamRegs)
+        if (cv <= 0) return zero4();
+        const int last = cv > 3 ? 3 : cv - 1;
+        T t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __builtin_nontemporal_load(src + (int64_t)(k < last ? k : last) * P);
+        r.x = (float)t[0];
+        r.y = cv > 1 ? (float)t[1] : 0.0f;
+        r.z = cv > 2 ? (float)t[2] : 0.0f;
+        r.w = cv > 3 ? (float)t[3] : 0.0f;
+        return r;
+    }
     r.x = cv > 0 ? ld_stream(src) : 0.0f;   // cv <= 0: a quad of padding channels (C padded up to a supported count)
     r.y = cv > 1 ? ld_stream(src + P) : 0.0f;
     r.z = cv > 2 ? ld_stream(src + 2 * P) : 0.0f;
@@ -400,8 +429,22 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     }
     __syncthreads();
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if constexpr (sizeof(ST) == 2) if (f.pair16) {   // lanes 0..31: channel c, lanes 32..63: channel c+1 (store_rows16)
+        const int L = lane & 31, up = lane >> 5;
+        if (2 * L >= wave_nlive(d.P)) return;
+        ST *row = obase + wave_p0() + 2 * L;
+#pragma unroll
+        for (int c0 = 0; c0 < C; c0 += 2) {
+            const int c = c0 + up;
+            const float2 v = *reinterpret_cast<const float2 *>(ot + c * OUT_LD + 2 * L);
+            if (c < d.C)
+                __builtin_nontemporal_store(bits16<ST>(v.x) | (bits16<ST>(v.y) << 16),
+                                            reinterpret_cast<uint32_t *>(row + (int64_t)c * d.P));
+        }
+        return;
+    }
     if (p < d.P) {
-        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int c = 0; c < C; ++c)
             if (c < d.C) st_stream_wt(obase + (int64_t)c * d.P + p, ot[c * OUT_LD + lane]);
@@ -417,15 +460,21 @@ struct Sample2 {
     uint32_t node[4];  // node index (y*W + x) inside one n; NO_NODE when zero-padded
     float W[4];
 
-    template <int KERNEL, int ORDER>
-    __device__ __forceinline__ void load(const float *grid, const float *offset, const Dims &d, const Flags &f) {
+    float2 g;          // the coordinates as loaded (begin), consumed by finish
+    // begin: which sample, and its coordinate load goes out; finish: the geometry.  The kernels issue their cotangent
+    // stream loads in between, so that one memory round trip covers both (a wave used to wait for its coordinates,
+    // work out the geometry and only then ask for the streams).
+    __device__ __forceinline__ void begin(const float *grid, const Dims &d) {
         n = blockIdx.y;
         int64_t pp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         live = pp < d.P;
         p = live ? pp : d.P - 1;
         s = (int64_t)n * d.P + p;
+        g = *reinterpret_cast<const float2 *>(grid + s * 2);
+    }
+    template <int KERNEL, int ORDER>
+    __device__ __forceinline__ void finish(const float *offset, const Dims &d, const Flags &f) {
         float off = offset[n];
-        float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
         ax[0] = make_axis<KERNEL, ORDER>(g.x, d.size[0], f, f.align, off);
         ax[1] = make_axis<KERNEL, ORDER>(g.y, d.size[1], f, f.align, off);
 #pragma unroll
@@ -467,6 +516,74 @@ __device__ __forceinline__ void store_stream(T *dst, int64_t P, const float4 (&o
         if (cv > 3) st_stream_wt(p + 3 * P, o[q].w);
     }
 }
+template <int CQ>
+__device__ __forceinline__ void put_payload(float *row, const float4 (&g)[CQ]);
+// 16-bit stream <-> the wave's LDS rows without going through lane = sample registers: lanes 0..31 take the 32 sample
+// pairs of channel c, lanes 32..63 those of channel c+1 -- every instruction moves two contiguous 128-byte runs, each
+// covered by consecutive lanes.  `chan0_n` = channel 0 of this n at sample 0.
+template <int CQ, typename T>
+__device__ __forceinline__ void store_rows16(const float *stage, int stride, T *base, int64_t P, int nlive, int C) {
+    const int lane = threadIdx.x & 63, L = lane & 31, up = lane >> 5;
+    if (2 * L >= nlive) return;
+    const float *r0 = stage + (2 * L) * stride + up;
+#pragma unroll
+    for (int i = 0; i < 2 * CQ; ++i) {
+        const int c = 2 * i + up;
+        const uint32_t w = bits16<T>(r0[2 * i]) | (bits16<T>(r0[stride + 2 * i]) << 16);
+        if (c < C) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(base + (int64_t)c * P + 2 * L));
+    }
+}
+// A cotangent stream on its way to the wave's stage rows, in two steps so that the loads can be issued early:
+// issue() sends the loads (no use of the data: nothing waits), to_rows() converts and writes the LDS rows -- this
+// lane's row, or with 16-bit pairs two channels of every row of the wave (callers sync before reading rows).
+template <int CQ, typename T>
+struct StreamRegs {
+    float4 g[CQ];          // fp32 streams
+    T t[4 * CQ];           // 16-bit streams, element path
+    uint32_t w[2 * CQ];    // 16-bit streams, dword path: lanes 0..31 hold the 32 sample pairs of channel 2i, lanes 32..63 of 2i+1
+    __device__ __forceinline__ void issue(const T *chan0_n, int64_t p, int64_t P, int C, bool pair16) {
+        if constexpr (sizeof(T) == 2) {
+            if (pair16) {
+                const int lane = threadIdx.x & 63, L = lane & 31, up = lane >> 5;
+                const bool live = 2 * L < wave_nlive(P);
+                const T *base = chan0_n + (live ? wave_p0() + 2 * L : 0);
+#pragma unroll
+                for (int i = 0; i < 2 * CQ; ++i) {
+                    const int c = 2 * i + up;
+                    w[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + (int64_t)(c < C ? c : C - 1) * P));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4 * CQ; ++k) t[k] = __builtin_nontemporal_load(chan0_n + p + (int64_t)(k < C ? k : C - 1) * P);
+            }
+        } else {
+            load_stream<CQ>(chan0_n + p, P, g, C);
+        }
+    }
+    __device__ __forceinline__ void to_rows(float *stage, int stride, int off, int64_t P, int C, bool pair16) {
+        const int lane = threadIdx.x & 63;
+        if constexpr (sizeof(T) == 2) {
+            if (pair16) {
+                const int L = lane & 31, up = lane >> 5;
+                const bool live = 2 * L < wave_nlive(P);
+                float *r0 = stage + off + (2 * L) * stride + up;
+#pragma unroll
+                for (int i = 0; i < 2 * CQ; ++i) {
+                    const bool ok = live && 2 * i + up < C;
+                    r0[2 * i] = ok ? half_of<T>(w[i], false) : 0.0f;
+                    r0[stride + 2 * i] = ok ? half_of<T>(w[i], true) : 0.0f;
+                }
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+                g[q] = make_float4(4 * q < C ? (float)t[4 * q] : 0.0f, 4 * q + 1 < C ? (float)t[4 * q + 1] : 0.0f,
+                                   4 * q + 2 < C ? (float)t[4 * q + 2] : 0.0f, 4 * q + 3 < C ? (float)t[4 * q + 3] : 0.0f);
+        }
+        put_payload<CQ>(stage + lane * stride + off, g);
+    }
+};
+
 // fat row of sample s: payload(s) then coefficient record(s), contiguous, 16-byte aligned.
 // A lane first puts its row into the wave's LDS stage; flush_rows then streams the wave's 64 rows
 // (one contiguous 64*STRIDE*4-byte block of the p-ordered array) with consecutive lanes writing
@@ -535,13 +652,18 @@ __device__ __forceinline__ float q_reduce(float x) {
     return x;
 }
 template <int CQ, typename T>
-__device__ __forceinline__ void q_store_rows(const float *stage, int stride, T *dst, int64_t P, bool live, int C) {
+__device__ __forceinline__ void q_store_rows(const float *stage, int stride, T *chan0_n, int64_t p, int64_t P, bool live,
+                                             int C, bool pair16) {
+    if constexpr (sizeof(T) == 2) if (pair16) {
+        store_rows16<CQ>(stage, stride, chan0_n + wave_p0(), P, wave_nlive(P), C);
+        return;
+    }
     if (!live) return;
     const float *row = stage + (threadIdx.x & 63) * stride;
     float4 o[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) o[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
-    store_stream<CQ, T>(dst, P, o, C);
+    store_stream<CQ, T>(chan0_n + p, P, o, C);
 }
 
 // first backward.  LDS stage row = the fat row [g | W0..W3] (flushed when WANT_ROWS: grad_input is wanted);
@@ -558,12 +680,13 @@ __global__ __launch_bounds__(256) void point_backward(const ST *__restrict__ gOu
     float *co = rec + QREC;
     const int lane = threadIdx.x & 63;
     Sample2 sm;
-    sm.load<KERNEL, 1>(grid, offset, d, f);
+    sm.begin(grid, d);
     {
-        float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
+        StreamRegs<CQ, ST> sg;
+        sg.issue(gOut + (int64_t)sm.n * d.go_ns, sm.p, d.P, d.C, f.pair16);
+        sm.finish<KERNEL, 1>(offset, d, f);
+        sg.to_rows(stage, STRIDE, 0, d.P, d.C, f.pair16);
         float *row = stage + lane * STRIDE;
-        put_payload<CQ>(row, g);
         if (WANT_ROWS) *reinterpret_cast<float4 *>(row + C) = make_float4(sm.W[0], sm.W[1], sm.W[2], sm.W[3]);
         co[lane] = sm.ax[0].w[0];
         co[64 + lane] = sm.ax[0].w[1];
@@ -615,13 +738,14 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     float *co = rec + QREC;
     const int lane = threadIdx.x & 63;
     Sample2 sm;
-    sm.load<KERNEL, 2>(grid, offset, d, f);
+    sm.begin(grid, d);
     {
         float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
-        float4 g[CQ];
-        load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
+        StreamRegs<CQ, ST> sg;
+        sg.issue(gOut + (int64_t)sm.n * d.go_ns, sm.p, d.P, d.C, f.pair16);
+        sm.finish<KERNEL, 2>(offset, d, f);
+        sg.to_rows(stage, STRIDE, 0, d.P, d.C, f.pair16);
         float *row = stage + lane * STRIDE;
-        put_payload<CQ>(row, g);
         float Dm[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -681,7 +805,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
         }
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P + sm.p, d.P, sm.live, d.C);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P, sm.p, d.P, sm.live, d.C, f.pair16);
     if (sm.live) *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(rec[4 * 64 + lane], rec[5 * 64 + lane]);
 }
 
@@ -702,10 +826,14 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
     float *rec = stage + 64 * STRIDE;
     const int lane = threadIdx.x & 63;
     Sample2 sm;
-    sm.load<KERNEL, 2>(grid, offset, d, f);
+    sm.begin(grid, d);
     {
         float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
         float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
+        StreamRegs<CQ, ST> sg, sh;
+        if (!LEAN) sg.issue(gOut + (int64_t)sm.n * d.go_ns, sm.p, d.P, d.C, f.pair16);
+        if (TWO) sh.issue(hO + (int64_t)sm.n * d.ho_ns, sm.p, d.P, d.C, f.pair16);
+        sm.finish<KERNEL, 2>(offset, d, f);
         float Dm[4], Em[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -714,15 +842,9 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
             if (f.exact) Em[a] = fmaf(sm.mixed2(a), hg.x * cg.y + hg.y * cg.x, Em[a]);
         }
         float *row = stage + lane * STRIDE;
-        if (!LEAN) {
-            float4 g[CQ];
-            load_stream<CQ>(gOut + (int64_t)sm.n * d.go_ns + sm.p, d.P, g, d.C);
-            put_payload<CQ>(row, g);
-        }
+        if (!LEAN) sg.to_rows(stage, STRIDE, 0, d.P, d.C, f.pair16);
         if (TWO) {
-            float4 h[CQ];
-            load_stream<CQ>(hO + (int64_t)sm.n * d.ho_ns + sm.p, d.P, h, d.C);
-            put_payload<CQ>(row + (LEAN ? 0 : C), h);
+            sh.to_rows(stage, STRIDE, LEAN ? 0 : C, d.P, d.C, f.pair16);
             *reinterpret_cast<float4 *>(row + EOFF + 4) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
         }
         *reinterpret_cast<float4 *>(row + EOFF) = make_float4(Em[0], Em[1], Em[2], Em[3]);
@@ -748,7 +870,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         *reinterpret_cast<float4 *>(row + 4 * q) = acc;   // over the (already flushed) gOut quad
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P + sm.p, d.P, sm.live, d.C);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P, sm.p, d.P, sm.live, d.C, f.pair16);
 }
 
 // ------------------------------------------------------------------------------------------------

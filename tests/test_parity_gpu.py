@@ -420,15 +420,15 @@ def test_other_float_dtypes_on_gpu(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("d,C", [(2, 16), (2, 6), (3, 8)])
-def test_native_half_streams(dtype, d, C):
+@pytest.mark.parametrize("d,C,P", [(2, 16, 40000), (2, 6, 40000), (3, 8, 40000), (2, 16, 39999), (2, 7, 40002), (2, 3, 40000)])
+def test_native_half_streams(dtype, d, C, P):
     """float16 / bfloat16 tensors on the fast paths: the channel-major streams (output, grad_output, grad_grad_out,
     grad_out_ggout) are read and written in that type by the kernels (CS_STREAM_F16 / CS_STREAM_BF16; the reference
     dispatches half too, 2d.cu:905, :948, :1009, :1076), fp32 arithmetic in between.  Every stage is compared with the
     fp32 op on the same numbers: the inputs are representable in `dtype`, so results differ by the rounding of the
     16-bit OUTPUTS only (fp32 outputs -- grad_grid, the input-shaped gradients -- agree to fp32 accuracy)."""
     eps = 1e-3 if dtype == torch.float16 else 8e-3
-    N, P = 2, 40000
+    N = 2
     sp = (40, 33) if d == 2 else (9, 11, 7)
     t = _case(d, N, C, sp, P, seed=5150 + C, spread=1.1)
     off = offsets(N, True).to(DEV)
@@ -444,11 +444,21 @@ def test_native_half_streams(dtype, d, C):
             out16 = ops.forward(inp, grid, off, 0, True, 0, True, ctx=s16, out_dtype=dtype)
             out32 = ops.forward(inp, grid, off, 0, True, 0, True, ctx=s32)
             assert out16.dtype == dtype and rel_err(out16, out32) <= eps
+            # same fp32 arithmetic, one rounding at the store: bit-identical to rounding the fp32 result (this pins the
+            # lane-pair dword path of even P -- cs_tiled.cuh st_pair16 -- as much as the element path of odd P)
+            assert d == 3 or torch.equal(out16, out32.to(dtype))   # (3D: the fp32 call may take another fast path)
             gI16, gG16 = ops.backward(gO16, inp, grid, off, 0, True, True, 0, True, ctx=s16)
             gI32, gG32 = ops.backward(gO32, inp, grid, off, 0, True, True, 0, True, ctx=s32)
             assert gI16.dtype == torch.float32
             assert_close(gI16, gI32, "half streams: grad_input")
             assert_close(gG16, gG32, "half streams: grad_grid")
+            # a cotangent that starts on an odd 16-bit element cannot be moved as dwords: the element path must give
+            # exactly what the lane-pair path gave
+            odd = torch.empty(gO16.numel() + 1, dtype=dtype, device=DEV)[1:].view(gO16.shape).copy_(gO16)
+            assert odd.data_ptr() % 4 == 2
+            gIo, gGo = ops.backward(odd, inp, grid, off, 0, True, True, 0, True)
+            gIa, gGa = ops.backward(gO16, inp, grid, off, 0, True, True, 0, True)
+            assert torch.equal(gGo, gGa) and rel_err(gIo, gIa) <= 1e-6
             b16 = ops.backward_backward(None, cG, inp, grid, gO16, off, 0, True, False, 0, True, ctx=s16)
             b32 = ops.backward_backward(None, cG, inp, grid, gO32, off, 0, True, False, 0, True, ctx=s32)
             assert_close(b16[0], b32[0], "half streams: second-backward grad_input")

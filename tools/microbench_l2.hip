@@ -60,6 +60,56 @@ __global__ __launch_bounds__(256) void read4(const float *__restrict__ src, int6
     }
     if (r == -12345.f) out[0] = r;
 }
+// 16-bit planes (0.5 GiB): how should lanes share them?  n = elements in all 16 planes, block = 256 samples unless noted
+__global__ __launch_bounds__(256) void read2(const uint16_t *__restrict__ src, int64_t n, float *out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 2-byte load per lane and plane (128 B per wave instruction)
+    const int64_t plane = n / 16;
+    uint32_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r += __builtin_nontemporal_load(src + (int64_t)c * plane + i);
+    if (r == 0x12345u) out[0] = r;
+}
+__global__ __launch_bounds__(256) void read2_halves(const uint16_t *__restrict__ src, int64_t n, float *out) {
+    // lanes 0..31: sample pairs of plane c, lanes 32..63: of plane c+1 (two 128-B runs per instruction, 8 loads per lane)
+    const int lane = threadIdx.x & 63, L = lane & 31, up = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63), plane = n / 16;
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r += __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + (int64_t)(2 * i + up) * plane + p0 + 2 * L));
+    if (r == 0x12345u) out[0] = r;
+}
+__global__ __launch_bounds__(256) void read2_rows(const uint16_t *__restrict__ src, int64_t n, float *out) {
+    // wave w takes planes w, w+4, w+8, w+12 for the block's 256 samples: 8 B per lane, 512 contiguous bytes per instruction
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 256, plane = n / 16;
+    uint32_t r = 0;
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src + (int64_t)(w + 4 * i) * plane + p0 + 4 * lane));
+        r += t.x + t.y;
+    }
+    if (r == 0x12345u) out[0] = r;
+}
+__global__ __launch_bounds__(256) void read2_wide(const uint16_t *__restrict__ src, int64_t n, float *out) {
+    // block = 512 samples, lane = sample pair: one dword per lane and plane (256 B per wave instruction, 16 loads per lane)
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t plane = n / 16;
+    uint32_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r += __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + (int64_t)c * plane) + i);
+    if (r == 0x12345u) out[0] = r;
+}
+__global__ __launch_bounds__(256) void read4_half(const float *__restrict__ src, int64_t n, float *out) {
+    // control: fp32 planes, 8 of them (the same 0.5 GiB, the product's fp32 pattern)
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t plane = n / 8;
+    float r = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r += __builtin_nontemporal_load(src + (int64_t)c * plane + i);
+    if (r == -12345.f) out[0] = r;
+}
 __global__ __launch_bounds__(256) void read16(const v4f *__restrict__ src, int64_t n4, float *out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float r = 0.f;
@@ -267,6 +317,12 @@ int main(int argc, char **argv) {
     dim3 gg((unsigned)(P * 4 / 256), 16);
     TIME("gather64   2^24 samples x 4 rows of 64 B, table by table (L2 hits)", (gather64<<<gg, 256>>>(table, nodes, W, P, dout)));
     TIME("read4      1 GiB in, 4 B/lane nontemporal (16 planes, as the product streams)", (read4<<<S / 256, 256>>>((const float *)src, S * 16, dout)));
+    TIME("read2      0.5 GiB in, 16 planes of 16-bit elements, 2 B/lane", (read2<<<S / 256, 256>>>((const uint16_t *)src, S * 16, dout)));
+    TIME("read2h     the same planes, dwords: lanes 0..31 plane c, lanes 32..63 plane c+1", (read2_halves<<<S / 256, 256>>>((const uint16_t *)src, S * 16, dout)));
+    TIME("read2r     the same planes, a wave takes whole 512-B block rows (8 B/lane, 4 planes per wave)", (read2_rows<<<S / 256, 256>>>((const uint16_t *)src, S * 16, dout)));
+    TIME("read2w     the same planes, 512 samples per block: lane = sample pair, one dword per plane", (read2_wide<<<S / 512, 256>>>((const uint16_t *)src, S * 16, dout)));
+    TIME("read4half  control: 0.5 GiB as 8 fp32 planes, 4 B/lane", (read4_half<<<S / 256, 256>>>((const float *)src, S * 8, dout)));
+    if (argc > 1 && !strcmp(argv[1], "half")) return 0;
     TIME("read16     1 GiB in, 16 B/lane nontemporal", (read16<<<n4 / 256, 256>>>(src, n4, dout)));
     TIME("write4     1 GiB out, 4 B/lane sc1 stores (as the product outputs)", (write4<<<S / 256, 256>>>((float *)dst, S * 16)));
     TIME("write4p    1 GiB out, 4 B/lane plain stores", (write4_plain<<<S / 256, 256>>>((float *)dst, S * 16)));
