@@ -370,6 +370,11 @@ def main():
                 "what": "configs[2]: CosineSampler2d.apply -> sum over n -> MLP -> u_x,u_y -> u_xx,u_yy -> "
                         "d mean((u_xx+u_yy+4u)^2)/d cells, all through torch.autograd (incl. its .contiguous() "
                         "copies of the expanded gradients and the MLP), same N,C,H,W,P"}
+            ms_b = helmholtz_step(N, C, H, P, dev, broadcast_grid=True)
+            line["pixel_helmholtz_autograd"]["ms_per_step_broadcast_grid"] = ms_b
+            line["pixel_helmholtz_autograd"]["broadcast_grid"] = (
+                "the same step with the points handed over once, a (1,1,P,2) grid (CS_GRID_BROADCAST) instead of "
+                "grid.repeat(N,1,1,1): no 128 MiB repeat, its backward sums are taken by the op")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, C, H)
         print(json.dumps(line), flush=True)

@@ -31,9 +31,10 @@ EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
+GRID_BROADCAST = 0x4000                   # CS_GRID_BROADCAST, OR-ed into `kernel` / the plan builders' `flags`
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
 _lib = None
 
@@ -67,11 +68,11 @@ def load():
     lib.cs2d_plan_bytes.restype = _c_sz
     lib.cs2d_plan_bytes.argtypes = [_c_i64] * 5
     lib.cs2d_plan_build.restype = _c_int
-    lib.cs2d_plan_build.argtypes = [_c_f, _c_f, _c_f, _c_sz] + [_c_i64] * 5 + [_c_int] * 3 + [_c_f]
+    lib.cs2d_plan_build.argtypes = [_c_f, _c_f, _c_f, _c_sz] + [_c_i64] * 5 + [_c_int] * 4 + [_c_f]
     lib.cs3d_plan_bytes.restype = _c_sz
     lib.cs3d_plan_bytes.argtypes = [_c_i64] * 6
     lib.cs3d_plan_build.restype = _c_int
-    lib.cs3d_plan_build.argtypes = [_c_f, _c_f, _c_f, _c_sz] + [_c_i64] * 6 + [_c_int] * 3 + [_c_f]
+    lib.cs3d_plan_build.argtypes = [_c_f, _c_f, _c_f, _c_sz] + [_c_i64] * 6 + [_c_int] * 4 + [_c_f]
     lib.cs_debug_force_path.restype = None
     lib.cs_debug_force_path.argtypes = [_c_int]
     if lib.cs_abi_version() != ABI_VERSION:

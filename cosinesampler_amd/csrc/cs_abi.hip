@@ -37,7 +37,8 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     const int exact = (kernel & CS_KERNEL_EXACT_MIXED) ? 1 : 0;
     if ((kernel & CS_STREAM_F16) && (kernel & CS_STREAM_BF16)) return CS_ERR_INVALID;
     pb.sdt = (kernel & CS_STREAM_F16) ? 1 : (kernel & CS_STREAM_BF16) ? 2 : 0;
-    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16);
+    const bool grid_bc = (kernel & CS_GRID_BROADCAST) != 0;
+    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST);
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
     // node indices and sizes are kept in 32-bit registers; element offsets are 64-bit
     if (N > INT32_MAX || C > INT32_MAX || D > (1 << 28) || H > (1 << 28) || W > (1 << 28)) return CS_ERR_UNSUPPORTED;
@@ -56,6 +57,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.d.tab_ns = 1;          // gathers read the caller's NC[D]HW tensor unless a stage switches to a channels-last copy
     pb.d.tab_cs = pb.d.vol;
     pb.d.go_ns = pb.d.ho_ns = C * P;   // contiguous cotangents unless the entry point is given a layout
+    pb.d.grid_ns = grid_bc ? 0 : P;
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
@@ -971,9 +973,10 @@ size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
 
 int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
                     int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int multicell,
-                    void *stream) {
+                    int flags, void *stream) {
     Problem pb;
-    int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, 0, multicell, stream);
+    if (flags & ~CS_GRID_BROADCAST) return CS_ERR_INVALID;
+    int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, flags, multicell, stream);
     if (rc) return rc;
     if (!tiled_applies(2, N, C, H, W, P)) return CS_ERR_UNSUPPORTED;
     if (!grid || !offset || !plan) return CS_ERR_INVALID;
@@ -989,9 +992,10 @@ size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, in
 
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
                     int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners, int multicell,
-                    void *stream) {
+                    int flags, void *stream) {
     Problem pb;
-    int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, 0, multicell, stream);
+    if (flags & ~CS_GRID_BROADCAST) return CS_ERR_INVALID;
+    int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, flags, multicell, stream);
     if (rc) return rc;
     if (!rows_cl_applies(3, N, C, P, D * H * W) || !dense3_applies(N, C, D, H, W, P)) return CS_ERR_UNSUPPORTED;
     if (!grid || !offset || !plan) return CS_ERR_INVALID;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void plan_count3(const float *__restrict__ gri
     for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
-            Cell3 q = locate3(grid + ((int64_t)n * d.P + p) * 3, d, f, off, pl);
+            Cell3 q = locate3(grid + d.gpt(n, p) * 3, d, f, off, pl);
             if (q.valid) atomicAdd(&hist[q.bin], 1u);
         }
     }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void plan_scatter3(const float *__restrict__ g
         int64_t p = p0 + i;
         if (p < d.P) {
             int64_t s = (int64_t)n * d.P + p;
-            Cell3 q = locate3(grid + s * 3, d, f, off, pl);
+            Cell3 q = locate3(grid + d.gpt(n, p) * 3, d, f, off, pl);
             if (q.valid) pl.sorted[atomicAdd(&cursor[q.bin], 1u)] = (uint32_t)s;
         }
     }

@@ -30,6 +30,10 @@ struct Dims {
     // channels-last copy made by pack_channels_last (one node = one contiguous C-float row)
     int64_t tab_ns, tab_cs;
     int64_t go_ns, ho_ns;   // elements between consecutive n of gOut / hO: C*P, or 0 for an n-broadcast (expanded) tensor
+    // points between consecutive n of grid, grad_out_grid and grad_out_ggrid: P, or 0 when ONE set of P points serves
+    // every n (CS_GRID_BROADCAST: PIXEL's grid.repeat(N, ...), test/test_2d.py:38, without the repeat)
+    int64_t grid_ns;
+    __host__ __device__ __forceinline__ int64_t gpt(int n, int64_t p) const { return (int64_t)n * grid_ns + p; }
 };
 
 template <int DIM>
@@ -52,7 +56,7 @@ struct Sample {
         n = (int)(s / d.P);
         p = s - (int64_t)n * d.P;
         float off = offset[n];
-        const float *g = grid + s * DIM;
+        const float *g = grid + d.gpt(n, p) * DIM;
         float gc[DIM];
         if (DIM == 2) {
             float2 v = *reinterpret_cast<const float2 *>(g);
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
     if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
     float cg[DIM];
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[((int64_t)sm.n * d.P + sm.p) * DIM + j] : 0.0f;
+    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[d.gpt(sm.n, sm.p) * DIM + j] : 0.0f;
 
     float W[NC], Dm[NC], F[DIM][NC], Sg[DIM][NC];
     sm.weights(W);
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
     float cg[DIM], hg[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        int64_t o = ((int64_t)sm.n * d.P + sm.p) * DIM + j;
+        int64_t o = d.gpt(sm.n, sm.p) * DIM + j;
         cg[j] = cG ? cG[o] : 0.0f;
         hg[j] = hG ? hG[o] : 0.0f;
     }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void direct_bbb_grid(
     constexpr int NC = 1 << DIM;
     Sample<DIM> sm;
     if (!sm.template load<KERNEL, 2>(grid, offset, d, f, f.align)) return;
-    const int64_t so = ((int64_t)sm.n * d.P + sm.p) * DIM;
+    const int64_t so = d.gpt(sm.n, sm.p) * DIM;
     float cg[DIM], hg[DIM], d3[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void direct_bbb_grid(
         float r = 0.0f;
 #pragma unroll
         for (int a = 0; a < NC; ++a) r = fmaf(A[l][a], dg[a], fmaf(B[l][a], dh[a], r));
-        gGrid3[so + l] = r;
+        gGrid3[((int64_t)sm.n * d.P + sm.p) * DIM + l] = r;   // results are per (n, p) whatever the grid's layout
     }
 }
 
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
     const int xbit = PAIR ? (int)((t >> logC) & 1) : 0;   // PAIR: this lane's nodes are the ones on its x side
     Sample<DIM> sm;
     if (!sm.template load_at<KERNEL, (MODE == 0 ? 0 : (MODE == 1 ? 1 : 2))>(t >> (logC + (PAIR ? 1 : 0)), grid, offset, d, f, f.align)) return;
-    const int64_t so = ((int64_t)sm.n * d.P + sm.p) * DIM;
+    const int64_t so = d.gpt(sm.n, sm.p) * DIM;
     float cg[DIM], hg[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     if (live) {
     float cg[DIM];
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[((int64_t)sm.n * d.P + sm.p) * DIM + j] : 0.0f;
+    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[d.gpt(sm.n, sm.p) * DIM + j] : 0.0f;
     float W[NC], Dm[NC], F[DIM][NC], Sg[DIM][NC];
     sm.weights(W);
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
     for (int a = 0; a < NC; ++a) Em[a] = Dm[a] = 0.0f;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        int64_t o = ((int64_t)sm.n * d.P + sm.p) * DIM + j;
+        int64_t o = d.gpt(sm.n, sm.p) * DIM + j;
         float cgj = cG ? cG[o] : 0.0f;
         float hgj = hG ? hG[o] : 0.0f;
         float e = cgj * hgj;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void plan_count(const float *__restrict__ grid
     for (int i = threadIdx.x; i < pl.chunk; i += 256) {
         int64_t p = p0 + i;
         if (p < d.P) {
-            float2 g = *reinterpret_cast<const float2 *>(grid + ((int64_t)n * d.P + p) * 2);
+            float2 g = *reinterpret_cast<const float2 *>(grid + d.gpt(n, p) * 2);
             Geo2 q = locate(g.x, g.y, d, f, off, pl.ntx);
             if (q.valid) atomicAdd(&hist[q.bin(pl)], 1u);
         }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
         int64_t p = p0 + i;
         if (p < d.P) {
             int64_t s = (int64_t)n * d.P + p;
-            float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
+            float2 g = *reinterpret_cast<const float2 *>(grid + d.gpt(n, p) * 2);
             Geo2 q = locate(g.x, g.y, d, f, off, pl.ntx);
             if (q.valid) {
                 uint32_t r = atomicAdd(&cursor[q.bin(pl)], 1u);
@@ -322,9 +322,8 @@ __device__ __forceinline__ void point_phase1(float *rec, const float *grid, cons
     const int n = blockIdx.y;
     int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= d.P) p = d.P - 1;
-    const int64_t s = (int64_t)n * d.P + p;
     const float off = offset[n];
-    float2 g = *reinterpret_cast<const float2 *>(grid + s * 2);
+    float2 g = *reinterpret_cast<const float2 *>(grid + d.gpt(n, p) * 2);
     Axis ax = make_axis<KERNEL, 0>(g.x, d.size[0], f, align, off);
     Axis ay = make_axis<KERNEL, 0>(g.y, d.size[1], f, align, off);
     uint32_t *ru = reinterpret_cast<uint32_t *>(rec);
@@ -470,7 +469,7 @@ struct Sample2 {
         live = pp < d.P;
         p = live ? pp : d.P - 1;
         s = (int64_t)n * d.P + p;
-        g = *reinterpret_cast<const float2 *>(grid + s * 2);
+        g = *reinterpret_cast<const float2 *>(grid + d.gpt(n, p) * 2);
     }
     template <int KERNEL, int ORDER>
     __device__ __forceinline__ void finish(const float *offset, const Dims &d, const Flags &f) {
@@ -740,7 +739,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     Sample2 sm;
     sm.begin(grid, d);
     {
-        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
+        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + d.gpt(sm.n, sm.p) * 2) : make_float2(0.f, 0.f);
         StreamRegs<CQ, ST> sg;
         sg.issue(gOut + (int64_t)sm.n * d.go_ns, sm.p, d.P, d.C, f.pair16);
         sm.finish<KERNEL, 2>(offset, d, f);
@@ -828,8 +827,8 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
     Sample2 sm;
     sm.begin(grid, d);
     {
-        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + sm.s * 2) : make_float2(0.f, 0.f);
-        float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + sm.s * 2) : make_float2(0.f, 0.f);
+        float2 cg = cG ? *reinterpret_cast<const float2 *>(cG + d.gpt(sm.n, sm.p) * 2) : make_float2(0.f, 0.f);
+        float2 hg = hG ? *reinterpret_cast<const float2 *>(hG + d.gpt(sm.n, sm.p) * 2) : make_float2(0.f, 0.f);
         StreamRegs<CQ, ST> sg, sh;
         if (!LEAN) sg.issue(gOut + (int64_t)sm.n * d.go_ns, sm.p, d.P, d.C, f.pair16);
         if (TWO) sh.issue(hO + (int64_t)sm.n * d.ho_ns, sm.p, d.P, d.C, f.pair16);

@@ -80,8 +80,8 @@ def _problem(input, grid):
     dim = input.dim() - 2
     if dim not in (2, 3):
         raise RuntimeError("input must be (N,C,H,W) or (N,C,D,H,W), got %s" % (tuple(input.shape),))
-    if grid.dim() != dim + 2 or grid.shape[-1] != dim or grid.shape[0] != input.shape[0]:
-        raise RuntimeError("grid must be (N,%s%d) with N=%d, got %s"
+    if grid.dim() != dim + 2 or grid.shape[-1] != dim or grid.shape[0] not in (1, input.shape[0]):
+        raise RuntimeError("grid must be (N,%s%d) with N=%d (or N=1: one set of points for every n), got %s"
                            % ("Ho,Wo," if dim == 2 else "Do,Ho,Wo,", dim, input.shape[0], tuple(grid.shape)))
     if grid.device != input.device:
         raise RuntimeError("input and grid must be on the same device")
@@ -89,6 +89,23 @@ def _problem(input, grid):
     for s in grid.shape[1:-1]:
         P *= int(s)
     return dim, [int(s) for s in input.shape], P
+
+
+def grid_is_broadcast(input, grid):
+    """A (1, ..., dim) grid with N > 1 tables: the same points for every n (CS_GRID_BROADCAST) -- what PIXEL builds with
+    grid.repeat(N, 1, 1, 1) (reference test/test_2d.py:38), without the repeat.  Everything grid-shaped then has a
+    leading 1: grad_out_grid / grad_out_ggrid as given, and the grad_grid results, which are summed over n (the
+    gradient w.r.t. the shared points, i.e. what autograd makes of the repeat)."""
+    return grid.shape[0] == 1 and input.shape[0] > 1
+
+
+def _grid_result(grid, N, bc):
+    """where the kernels write a per-point result: always one row per (n, p)"""
+    return torch.empty((N,) + tuple(grid.shape[1:]), dtype=grid.dtype, device=grid.device) if bc else torch.empty_like(grid)
+
+
+def _grid_reduce(t, bc):
+    return t.sum(0, keepdim=True) if bc else t
 
 
 def _same(t, like_shape, name, device, stream=False):
@@ -165,8 +182,9 @@ class StepContext(object):
         return self._cl
 
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
+        bc = grid.shape[0] == 1 and shape[0] > 1
         key = self._key(grid) + (offset.data_ptr(),) + tuple(shape[2:]) + (int(padding_mode), bool(align_corners),
-                                                                            bool(multicell), _force_epoch)
+                                                                            bool(multicell), _force_epoch, shape[0])
         if self._plan_key != key:
             sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
             nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
@@ -176,7 +194,8 @@ class StepContext(object):
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
                 _lib.check(getattr(lib, "cs%dd_plan_build" % dim)(
                     grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, *sizes, int(padding_mode),
-                    int(bool(align_corners)), int(bool(multicell)), stream), "cs%dd_plan_build" % dim)
+                    int(bool(align_corners)), int(bool(multicell)), _lib.GRID_BROADCAST if bc else 0, stream),
+                    "cs%dd_plan_build" % dim)
                 self._plan = buf
         return self._plan
 
@@ -186,10 +205,12 @@ _force_epoch = 0
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None):
-    if not isinstance(kernel, int) or (kernel & ~(EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16)) not in (0, 1, 2):
+    if not isinstance(kernel, int) or (kernel & ~(EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST)) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
                         "got %r" % (kernel,))
+    if grid is not None and grid.shape[0] == 1 and shape[0] > 1:
+        kernel |= _lib.GRID_BROADCAST
     lib = _lib.load()
     fn = getattr(lib, "cs%dd_%s" % (dim, stage))
     D = shape[2] if dim == 3 else 1
@@ -273,11 +294,12 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     kernel, _ = _stream_kernel(kernel, grad_output)
     grad_input = torch.empty_like(input) if input_requires_grad else None
-    grad_grid = torch.empty_like(grid)
+    bc = grid_is_broadcast(input, grid)
+    grad_grid = _grid_result(grid, shape[0], bc)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
                             _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
           ctx, input, grid, offset, want_plan=bool(input_requires_grad), go_ns=go_ns, grad_output=grad_output)
-    return grad_input, grad_grid
+    return grad_input, _grid_reduce(grad_grid, bc)
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
@@ -297,14 +319,15 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     kernel, _ = _stream_kernel(kernel, grad_output)
     grad_input = torch.empty_like(input) if want_grad_input else None
-    grad_grid = torch.empty_like(grid)
+    bc = grid_is_broadcast(input, grid)
+    grad_grid = _grid_result(grid, shape[0], bc)
     grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
     _call("backward_backward", dim,
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
           want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns, grad_output=grad_output)
-    return grad_input, grad_grid, grad_grad_out
+    return grad_input, _grid_reduce(grad_grid, bc), grad_grad_out
 
 
 def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, padding_mode,
@@ -368,7 +391,10 @@ def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_g
     ho_ns = None
     if grad_out_ggout is not None:
         ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
-    grad_grid3 = torch.empty_like(grid)
+    bc = grid_is_broadcast(input, grid)
+    grad_grid3 = _grid_result(grid, shape[0], bc)
+    if bc:
+        kernel |= _lib.GRID_BROADCAST
     lib = _lib.load()
     CP = shape[1] * P
     layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns)
@@ -378,4 +404,4 @@ def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_g
             _ptr(offset), _ptr(grad_grid3), *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel),
             int(bool(multicell)), layout, torch.cuda.current_stream(input.device).cuda_stream)
     _lib.check(rc, "cs%dd_bbb_grid" % dim)
-    return grad_grid3
+    return _grid_reduce(grad_grid3, bc)

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 7
+#define CS_ABI_VERSION 8
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -67,6 +67,12 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * (cs_half_streams_supported); elsewhere the calls return CS_ERR_UNSUPPORTED and the caller converts. */
 #define CS_STREAM_F16 0x1000
 #define CS_STREAM_BF16 0x2000
+/* OR-ed into `kernel` (and the `flags` of the plan builders; not in the reference, whose callers materialise
+ * grid.repeat(N, 1, 1, 1), test/test_2d.py:38): ONE set of P points serves every n.  `grid`, `grad_out_grid` and
+ * `grad_out_ggrid` are then [P, dim] arrays; the per-point OUTPUTS (grad_grid of the first and second backward) are
+ * still written per n, [N, P, dim] -- the gradient with respect to the shared points is their sum over n, which the
+ * caller takes (cosinesampler_amd/ops.py does).  Every path accepts it. */
+#define CS_GRID_BROADCAST 0x4000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
 /* OR-ed into the stage id: the call will pass grad_input == NULL (first / second backward only) -- nothing is
@@ -123,14 +129,16 @@ int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P);
 int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
                     int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
-                    int padding_mode, int align_corners, int multicell, void *stream);
+                    int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
+                    void *stream);
 
 /* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C in {1..4,8,16},
  * P >= 8 cells: the reference's test_3d.py shapes): samples binned by cell.  cs3d_plan_bytes returns 0 otherwise. */
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
                     int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
-                    int padding_mode, int align_corners, int multicell, void *stream);
+                    int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
+                    void *stream);
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables

@@ -199,3 +199,33 @@ def test_drop_in_package_names():
     import cosine_sampler_3d
     assert cosine_sampler_2d.CosineSampler2d is CosineSampler2d
     assert cosine_sampler_3d.CosineSampler3d is CosineSampler3d
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_broadcast_grid_through_the_function_chain(monkeypatch, d):
+    """A (1, ..., dim) grid = the same points for every n (PIXEL's grid.repeat(N, 1, 1, 1), reference test/test_2d.py:38,
+    without the repeat): the Function chain must give what the repeated grid gives, gradients w.r.t. the points summed
+    over n -- here with the oracle as the backend, on the GPU in tests/test_parity_gpu.py."""
+    oracle_backend.install(monkeypatch)
+    from cosinesampler_amd import CosineSampler3d
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    torch.manual_seed(5 + d)
+    N, C, P = 3, 2, 40
+    cells0 = torch.rand((N, C) + (6,) * d)
+    pts0 = torch.rand((1,) + (1,) * (d - 1) + (P, d)) * 1.8 - 0.9
+    res = []
+    for bc in (True, False):
+        cells = cells0.clone().requires_grad_(True)
+        pts = pts0.clone().requires_grad_(True)
+        grid = pts if bc else pts.repeat((N,) + (1,) * (d + 1))
+        out = Fn.apply(cells, grid, "zeros", True, "cosine", True)
+        assert out.shape == (N, C) + (1,) * (d - 1) + (P,)
+        u = torch.tanh(out.sum(0)).sum(0)
+        (u_g,) = torch.autograd.grad(u.sum(), pts, create_graph=True)
+        assert u_g.shape == pts.shape
+        (u_gg,) = torch.autograd.grad(u_g[..., 0].sum(), pts, create_graph=True)
+        loss = (u_gg[..., 0] ** 2).mean() + (u ** 2).mean()
+        (gc,) = torch.autograd.grad(loss, cells)
+        res.append((out.detach(), u_g.detach(), u_gg.detach(), gc))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)

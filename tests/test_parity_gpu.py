@@ -268,6 +268,84 @@ def test_expanded_cotangents_equal_contiguous_ones(d, C, force):
         ops.backward(gO_c.transpose(0, 1).contiguous().transpose(0, 1), inp, grid, off, 0, True, True, 0, True)
 
 
+@pytest.mark.parametrize("d,C,force,P", [(2, 16, 2, 30000), (2, 6, 2, 30000), (2, 16, 4, 30000), (2, 3, 0, 3000), (2, 40, 0, 3000),
+                                         (2, 4, 3, 40000), (3, 8, 2, 30000), (3, 3, 0, 2000), (3, 2, 2, 30000), (2, 5, 1, 3000),
+                                         (3, 4, 1, 3000)])
+@pytest.mark.parametrize("mc", [True, False])
+def test_broadcast_grid_equals_repeated_grid(d, C, force, P, mc):
+    """One set of P points for every n -- a (1, ..., dim) grid, CS_GRID_BROADCAST -- against the same points repeated N
+    times as PIXEL does (reference test/test_2d.py:38), on every execution path and every stage.  Per-sample results must
+    be the very same numbers; everything grid-shaped has a leading 1 and is the sum over n of the repeated run's."""
+    N = 3
+    sp = ((40, 33) if force != 3 else (16, 16)) if d == 2 else (9, 11, 7)
+    t = _case(d, N, C, sp, P, seed=77 + C + d)
+    off = offsets(N, mc).to(DEV)
+    inp, gOut, hO, cI = (_g(t[k]) for k in ("inp", "gOut", "hO", "cI"))
+    g1, cG1, hG1 = (_g(t[k][:1].contiguous()) for k in ("grid", "cG", "hG"))
+    rep = lambda x: x.repeat((N,) + (1,) * (x.dim() - 1))
+    gN, cGN, hGN = rep(g1), rep(cG1), rep(hG1)
+    ops.force_path(force)
+    try:
+        for shared in (False, True):
+            a, b = (ops.StepContext() if shared else None), (ops.StepContext() if shared else None)
+            assert torch.equal(ops.forward(inp, g1, off, 0, True, 0, mc, ctx=a), ops.forward(inp, gN, off, 0, True, 0, mc, ctx=b))
+            gI1, gG1 = ops.backward(gOut, inp, g1, off, 0, True, True, 0, mc, ctx=a)
+            gIN, gGN = ops.backward(gOut, inp, gN, off, 0, True, True, 0, mc, ctx=b)
+            assert gG1.shape == g1.shape
+            assert_close(gI1, gIN, "broadcast grid: grad_input")
+            assert_close(gG1, gGN.sum(0, keepdim=True), "broadcast grid: grad_grid")
+            assert_close(ops.backward(gOut, inp, g1, off, 0, True, False, 0, mc, ctx=a)[1], gGN.sum(0, keepdim=True),
+                         "broadcast grid: grad_grid alone")
+            b1 = ops.backward_backward(cI, cG1, inp, g1, gOut, off, 0, True, True, 0, mc, ctx=a)
+            bN = ops.backward_backward(cI, cGN, inp, gN, gOut, off, 0, True, True, 0, mc, ctx=b)
+            assert_close(b1[0], bN[0], "broadcast grid: second-backward grad_input")
+            assert_close(b1[1], bN[1].sum(0, keepdim=True), "broadcast grid: second-backward grad_grid")
+            assert torch.equal(b1[2], bN[2])
+            b1 = ops.backward_backward(None, cG1, inp, g1, gOut, off, 0, True, False, 0, mc, ctx=a, want_grad_input=False)
+            bN = ops.backward_backward(None, cGN, inp, gN, gOut, off, 0, True, False, 0, mc, ctx=b, want_grad_input=False)
+            assert b1[0] is None and torch.equal(b1[2], bN[2])
+            assert_close(b1[1], bN[1].sum(0, keepdim=True), "broadcast grid: second-backward grad_grid, no table gradient")
+            f1 = ops.bbb_fused(inp, g1, gOut, cG1, hG1, hO, off, 0, True, 0, mc, ctx=a)
+            fN = ops.bbb_fused(inp, gN, gOut, cGN, hGN, hO, off, 0, True, 0, mc, ctx=b)
+            assert_close(f1[0], fN[0], "broadcast grid: third-backward grad_input")
+            assert torch.equal(f1[1], fN[1])
+            k1 = ops.backward_backward_backward(inp, g1, gOut, cG1, hG1, off, 0, True, True, 0, mc, ctx=a)
+            kN = ops.backward_backward_backward(inp, gN, gOut, cGN, hGN, off, 0, True, True, 0, mc, ctx=b)
+            assert_close(k1[0], kN[0], "broadcast grid: K4 grad_input")
+            assert torch.equal(k1[1], kN[1])
+        e1 = ops.bbb_grid(inp, g1, gOut, cG1, hG1, hO, off, 0, True, 0 | ops.EXACT_MIXED, mc)
+        eN = ops.bbb_grid(inp, gN, gOut, cGN, hGN, hO, off, 0, True, 0 | ops.EXACT_MIXED, mc)
+        assert e1.shape == g1.shape
+        assert_close(e1, eN.sum(0, keepdim=True), "broadcast grid: third-order grid gradient")
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_broadcast_grid_through_autograd(d):
+    """The PIXEL pattern without the repeat: CosineSampler.apply(cells, grid_1) == CosineSampler.apply(cells,
+    grid_1.repeat(N, ...)) through three levels of autograd, gradients w.r.t. the points included."""
+    N, C, P = 4, 8, 20000
+    sp = (24, 31) if d == 2 else (7, 9, 8)
+    t = _case(d, N, C, sp, P, seed=4242 + d, spread=0.95)
+    Fn = CosineSampler2d if d == 2 else CosineSampler3d
+    res = []
+    for bc in (True, False):
+        cells = _g(t["inp"]).clone().requires_grad_(True)
+        pts = _g(t["grid"][:1]).clone().requires_grad_(True)
+        grid = pts if bc else pts.repeat((N,) + (1,) * (pts.dim() - 1))
+        out = Fn.apply(cells, grid, "zeros", True, "cosine", True)
+        u = torch.tanh(out.sum(0)).sum(0)                     # (1.., P)
+        (u_g,) = torch.autograd.grad(u.sum(), pts, create_graph=True)
+        (u_gg,) = torch.autograd.grad(u_g[..., 0].sum(), pts, create_graph=True)
+        loss = (u_gg[..., 0] ** 2).mean() + (u ** 2).mean()
+        (gc,) = torch.autograd.grad(loss, cells)
+        res.append((out.detach(), u_g.detach(), u_gg.detach(), gc))
+    for a, b, what in zip(res[0], res[1], ("output", "u_x", "u_xx", "d loss / d cells")):
+        assert_close(a, b, "broadcast grid through autograd: " + what, tol=2e-5)
+
+
 @pytest.mark.parametrize("d,C", [(2, 16), (2, 4), (3, 8)])
 def test_autograd_chain_on_fast_paths_vs_composite(d, C):
     """Large enough for the fast paths (2D: tiled, 3D: channels-last + row scatter) to be chosen by the

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for m in ${@:-2 4}; do
   rm -rf $R/gpurun_out/pp_$m
-  CS_FORCE=$m timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pp_$m -- python $R/tools/pipe.py > $R/gpurun_out/pp_$m.log 2>&1 || { echo "mode $m failed"; tail -5 $R/gpurun_out/pp_$m.log; exit 1; }
+  CS_FORCE=$m timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pp_$m -- python $R/tools/${PIPE:-pipe.py} > $R/gpurun_out/pp_$m.log 2>&1 || { echo "mode $m failed"; tail -5 $R/gpurun_out/pp_$m.log; exit 1; }
   echo "== force $m"
   python - $(ls $R/gpurun_out/pp_$m/*/*kernel_stats.csv | head -1) <<'PY'
 import csv,sys
