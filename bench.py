@@ -108,7 +108,7 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
                       "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
 
 
-def helmholtz_step(N, C, H, P, dev, steps=3):
+def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False):
     """BASELINE.json configs[2]: the PIXEL-style Helmholtz step driven entirely by torch.autograd
     (reference test/test_2d.py pattern): u = MLP(sum_n sampler(cells, grid)); u_x, u_y; u_xx, u_yy via the
     second backward; loss = mean((u_xx + u_yy + k^2 u)^2); d loss / d cells via the third backward.
@@ -123,7 +123,9 @@ def helmholtz_step(N, C, H, P, dev, steps=3):
     ones = torch.ones(P, 1, device=dev)
 
     def one():
-        grid = torch.cat([x, y], -1).view(1, 1, P, 2).repeat(N, 1, 1, 1)
+        grid = torch.cat([x, y], -1).view(1, 1, P, 2)
+        if not broadcast_grid:            # the reference pattern (test/test_2d.py:38); broadcast_grid: the same points
+            grid = grid.repeat(N, 1, 1, 1)   # handed over once, CS_GRID_BROADCAST (not expressible with the reference op)
         val = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
         u = torch.tanh(val.sum(0).view(C, -1).t() @ W1.t()) @ W2.t()
         u_x, u_y = torch.autograd.grad(u, (x, y), ones, create_graph=True)

@@ -801,8 +801,9 @@ def test_edge_shapes(d):
         ops.forward(inp.double(), grid.double(), multicell_offset(2, True, DEV), 0, True, 0, True)
     with pytest.raises(RuntimeError, match="floating-point"):   # ... and the autograd layer converts floats only
         Fn.apply(inp.long(), grid)
-    with pytest.raises(RuntimeError, match="grid must be"):
-        Fn.apply(inp, grid[:1])
+    with pytest.raises(RuntimeError, match="grid must be"):   # N of the grid: the table's, or 1 (the same points for every n)
+        Fn.apply(inp, torch.cat([grid, grid[:1]]))
+    assert Fn.apply(inp, grid[:1]).shape == (2, 3) + (1,) * (d - 1) + (9,)
 
 
 def _full_size_inputs(N=16, C=16, H=256, P=1 << 20):
