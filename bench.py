@@ -38,11 +38,11 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 # what each timed stage launches at this config (names as rocprofv3 prints them, profiles/round2_kernel_stats.csv);
 # a stage's HIP-event time is the sum of these plus the 64 MiB clear of its grad_input
 STAGE_KERNELS = {
-    "forward": ["cs::tiled::pack_channels_last", "cs::tiled::point_forward<0, 4>"],
-    "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward<0, 4, true>",
+    "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4, float>"],
+    "backward": ["cs::tiled::plan_count/scan_chunks/scan_tiles/scatter/tile_sort", "cs::tiled::point_backward<0, 4, true, float>",
                  "cs::tiled::tile_scatter<4, 0, true>"],
-    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2>", "cs::tiled::tile_scatter<4, 2, false>"],
-    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true>", "cs::tiled::tile_scatter<4, 3, false>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
+    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
 }
 
 

@@ -29,8 +29,20 @@ def rel(a, b):
     return float((a - b).abs().max()) / den
 
 
-def run(mod, t, off, pad, align, ke, mc, dev, shared):
+GRID_SHAPED = ("grid", "cG", "hG")
+GRID_RESULTS = ("gG", "gG0", "bbG", "bG0")
+
+
+def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
+    """bc: one set of points for every n.  The product (ops) is handed (1, ..., dim) tensors; the oracle, like the
+    reference, the repeated ones, and its grid-shaped results are summed over n."""
     x = {k: v.to(dev) for k, v in t.items()}
+    if bc:
+        N = x["inp"].shape[0]
+        for k in GRID_SHAPED:
+            x[k] = x[k][:1].contiguous()
+            if mod is cs_oracle:
+                x[k] = x[k].repeat((N,) + (1,) * (x[k].dim() - 1))
     off = off.to(dev)
     kw = {}
     if shared:
@@ -46,6 +58,9 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared):
     r["k4I"], r["k4O"] = mod.backward_backward_backward(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], off, pad, align,
                                                         True, ke, mc, **kw)
     r["fI"], r["fO"] = mod.bbb_fused(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], off, pad, align, ke, mc, **kw)
+    if bc and mod is cs_oracle:
+        for k in GRID_RESULTS:
+            r[k] = r[k].sum(0, keepdim=True)
     return r
 
 
@@ -60,6 +75,7 @@ for case in range(cases):
     pad, align, ke, mc = rng.choice([0, 1, 2]), rng.choice([True, False]), rng.choice([0, 1, 2]), rng.choice([True, False])
     force = rng.choice([0, 1, 2, 2, 2, 3, 4])
     shared = rng.choice([True, False])
+    bc = N > 1 and rng.random() < 0.25
     g = torch.Generator().manual_seed(seed * 100003 + case)
     inp = torch.rand((N, C) + sp, generator=g)
     spread = rng.choice([0.9, 1.0, 1.3])
@@ -71,10 +87,10 @@ for case in range(cases):
     t = dict(inp=inp, grid=grid, gOut=torch.randn(osh, generator=g), cI=torch.randn(inp.shape, generator=g),
              cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g), hO=torch.randn(osh, generator=g))
     off = multicell_offset(N, mc, "cpu")
-    want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False)
+    want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc)
     ops.force_path(force)
     try:
-        got = run(ops, t, off, pad, align, ke, mc, DEV, shared)
+        got = run(ops, t, off, pad, align, ke, mc, DEV, shared, bc)
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)
@@ -82,8 +98,8 @@ for case in range(cases):
     worst = max(errs, key=errs.get)
     if not all(torch.isfinite(v).all() for v in got.values()) or errs[worst] > 1e-5:
         bad += 1
-        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s -> %s %.3e"
-              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, worst, errs[worst]), flush=True)
+        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s bc=%s -> %s %.3e"
+              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, bc, worst, errs[worst]), flush=True)
     elif case % 25 == 0:
         print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d) worst %s %.1e" % (case, d, C, sp, P, force, worst, errs[worst]),
               flush=True)

@@ -54,15 +54,15 @@ T = 16 * 16 * 256 * 256 * 4      # the zero-fill of one grad_input (the launches
 plan = ["cs::tiled::plan_count", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiled::plan_scatter",
         "cs::tiled::plan_tile_sort"]
 stages = {
-    "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4>"],
-    "backward": plan + ["cs::tiled::point_backward<0, 4, true>", "cs::tiled::tile_scatter<4, 0, true>"],
-    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2>", "cs::tiled::tile_scatter<4, 2, false>"],
-    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true>", "cs::tiled::tile_scatter<4, 3, false>"],
+    "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4, float>"],
+    "backward": plan + ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
+    "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
+    "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
-    "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2>"],
-    "3d_backward": ["cs::cl::backward<3, 2, 2, 1>", "cs::unpack_cl4"],
-    "3d_backward_backward": ["cs::cl::backward_backward<3, 2, 2, false, 1>", "cs::unpack_cl4"],
-    "3d_bbb_fused": ["cs::cl::bbb<3, 2, 2, 1>", "cs::unpack_cl4"],
+    "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2, float>"],
+    "3d_backward": ["cs::cl::backward<3, 2, 2, 1, float>", "cs::unpack_cl4"],
+    "3d_backward_backward": ["cs::cl::backward_backward<3, 2, 2, false, 1, float>", "cs::unpack_cl4"],
+    "3d_bbb_fused": ["cs::cl::bbb<3, 2, 2, 1, float>", "cs::unpack_cl4"],
 }
 import bench
 out = {"source": "rocprofv3 --pmc, one pass per counter group, python bench.py --steps 1 --warmup 1 (tools/profile_round.sh %s); "
@@ -75,5 +75,21 @@ for st, ks in stages.items():
     out["bytes_per_launch"][st] = total(ks, "corrected") + extra
     out["raw"][st] = total(ks, "raw") + extra
     out["by_request_size"][st] = total(ks, "by_size") + extra
+# the Helmholtz step (tools/helmholtz_profile.py under --pmc, 4 steps): every kernel of the process, ours and torch's
+helm = {"ours": collections.defaultdict(float), "torch": collections.defaultdict(float)}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_helm_%s" % (tag, c), "*", "*counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            who = "ours" if ("cs::" in k or "zero_fill" in k or "_ZN2cs" in k) else "torch"
+            helm[who][r["Counter_Name"]] += float(r["Counter_Value"])
+if helm["ours"]:
+    HSTEPS = 4.0
+    out["pixel_helmholtz_autograd"] = {
+        who: {"raw": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / HSTEPS,
+              "corrected": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / HSTEPS} for who, v in helm.items()}
+    out["pixel_helmholtz_autograd"]["what"] = ("bytes per step of BASELINE configs[2] (N=16 C=16 256^2 P=2^20, reference "
+                                               "pattern with grid.repeat), sampler kernels vs torch's own (sum over n, MLP, "
+                                               "accumulations), tools/helmholtz_profile.py: 4 steps under --pmc")
 json.dump(out, open(os.path.join(ROOT, "profiles", "stage_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -19,3 +19,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc group $i ($set) failed"
   echo "pmc group $i done"
 done
+# the autograd-driven Helmholtz step alone (1 warm-up + 3 steps): kernel stats and the two byte counters over every kernel
+rm -rf $R/gpurun_out/prof_${TAG}_helm
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_helm -- python $R/tools/helmholtz_profile.py > $R/gpurun_out/prof_${TAG}_helm.log 2>&1 || echo "helmholtz kernel-trace failed"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/pmc_${TAG}_helm_$c
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_helm_$c -- python $R/tools/helmholtz_profile.py > $R/gpurun_out/pmc_${TAG}_helm_$c.log 2>&1 || echo "helmholtz pmc $c failed"
+  echo "helmholtz pmc $c done"
+done
