@@ -262,7 +262,7 @@ int row_scatter_into(const Problem &pb, const float *grid, const float *offset, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiled path (2D, C in {1..4, 8, 16, 32})
+// tiled path (2D, any C <= 32: run zero-padded to 4, 8, 16 or 32 channels, cpad)
 // ------------------------------------------------------------------------------------------------
 constexpr int64_t kTiledMinSamples = 1 << 16;  // below this the launch count matters more than atomics
 
@@ -602,7 +602,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3D with C in {1..4, 8, 16}: channels-last point kernels + fused row atomics, or the dense path for crowded tables
+// 3D with C <= 16 (zero-padded to 4, 8 or 16 channels): channels-last point kernels + fused row atomics, or the dense path for crowded tables
 // ------------------------------------------------------------------------------------------------
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     const int mode = g_force_path.load(std::memory_order_relaxed);

@@ -1,5 +1,5 @@
 // cs_points_cl.cuh -- point kernels for any dimensionality gathering float4 channel quads from the
-// channels-last copy of `input` (one node = one contiguous C-float row).  Used for 3D with C in {4,8,16}: a
+// channels-last copy of `input` (one node = one contiguous C-float row).  Used for 3D with C <= 16 (padded to 4, 8 or 16 channels): a
 // trilinear sample touches 8 node rows instead of 8*C separate lines of the NCDHW tensor.  They produce the
 // p-ordered outputs of a stage and, with SCATTER, the input-shaped gradient too: each lane leaves
 // [cotangent values | node coefficients | node ids] of its sample in LDS and the wave then adds whole node rows

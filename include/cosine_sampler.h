@@ -32,7 +32,9 @@
  *     offset, sizes and flags.  The library cannot check that they match (they live in device
  *     memory and nothing here synchronises): passing a stale one is undefined behaviour.  When
  *     NULL, a stage that wants them builds them inside `workspace` (cs_workspace_bytes accounts
- *     for it).  Problems outside the fast paths (channel counts other than 1..4, 8, 16 [, 32 in 2D], tiny S) ignore both.
+ *     for it).  Problems outside the fast paths (C > 32 in 2D / > 16 in 3D -- smaller counts run zero-padded to 4, 8, 16
+ *     or 32 channels --, tiny S) ignore both.
+ *   - grid (N,...,dim); with CS_GRID_BROADCAST in `kernel` a single (...,dim) set of points shared by every n.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
  *   - Thread-safe and re-entrant: the library keeps no mutable global state (the one exception is
@@ -132,7 +134,7 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
                     void *stream);
 
-/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C in {1..4,8,16},
+/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C <= 16 (run zero-padded to 4, 8 or 16 channels),
  * P >= 8 cells: the reference's test_3d.py shapes): samples binned by cell.  cs3d_plan_bytes returns 0 otherwise. */
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,

@@ -129,6 +129,18 @@ __global__ __launch_bounds__(256) void atomic_rows(float *dst, uint32_t slot_mas
     unsafeAtomicAdd(dst + (int64_t)slot * ALIGN + c, 1.0f);
 }
 
+// the same 64-byte row atomics with LOCALITY: a workgroup adds 256 rows to random slots of ONE 16 KiB window of the
+// accumulator (what a pass over cell-sorted samples of a 3D tile would do) -- do the line fills go away?
+__global__ __launch_bounds__(256) void atomic_rows_local(float *dst, uint32_t window_mask, int passes) {
+    const uint32_t window = hash32(blockIdx.x * 2654435761u + 11u) & window_mask;
+    const int c = threadIdx.x & 15;
+    for (int i = 0; i < passes; ++i) {
+        const uint32_t r = (uint32_t)i * 16u + (threadIdx.x >> 4);
+        const uint32_t slot = hash32((blockIdx.x * 4096u + r) * 2246822519u + 3u) & 255u;
+        unsafeAtomicAdd(dst + ((int64_t)window * 256 + slot) * 16 + c, 1.0f);
+    }
+}
+
 // gathers only, table by table without the 64-bit division of S1: blockIdx.y = n
 __global__ __launch_bounds__(256) void quad_gather_n(const float4 *table, int64_t nodes_per_n, int W, int64_t P, float *out) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -250,6 +262,8 @@ int main() {
         TIME("A2 2^24 row atomics, 16 lanes x 4 B = 64 B rows, 64 B aligned (pairs of the above)", (atomic_rows<16, 16><<<(R / 2) * 16 / 256, 256>>>(acc, (1u << 23) - 1, R / 2)));
         TIME("A3 2^24 row atomics, 16 lanes x 4 B = 64 B rows, 32 B aligned (half of them straddle)", (atomic_rows<16, 8><<<(R / 2) * 16 / 256, 256>>>(acc, (1u << 24) - 2, R / 2)));
         TIME("A4 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 128 B aligned", (atomic_rows<32, 32><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 22) - 1, R / 4)));
+        TIME("A6 2^24 64-B row atomics, each workgroup's 256 rows inside one random 16 KiB window", (atomic_rows_local<<<(R / 2) / 256, 256>>>(acc, (1u << 15) - 1, 16)));
+        TIME("A7 2^24 64-B row atomics, 64 rows per workgroup and window (4x as many workgroups)", (atomic_rows_local<<<(R / 2) / 64, 256>>>(acc, (1u << 15) - 1, 4)));
         TIME("A5 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 32 B aligned", (atomic_rows<32, 8><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 24) - 4, R / 4)));
     }
     return 0;
