@@ -141,6 +141,25 @@ __global__ __launch_bounds__(256) void atomic_rows_local(float *dst, uint32_t wi
     }
 }
 
+// LDS float atomics: a workgroup adds `adds` values per thread to hashed slots of a 13 KiB image (a 3D tile's 9x9x5 nodes
+// of 8 channels), then stores the image (so that nothing is optimised away).  RUN = 8: a lane adds 8 consecutive floats
+// (one node row of 8 channels), as a per-corner lane of a 3D scatter would.
+template <int RUN>
+__global__ __launch_bounds__(256) void lds_atomics(float *out, int adds) {
+    __shared__ float img[3240];
+    for (int i = threadIdx.x; i < 3240; i += 256) img[i] = 0.f;
+    __syncthreads();
+    uint32_t h = hash32(blockIdx.x * 256u + threadIdx.x + 1u);
+    for (int i = 0; i < adds; i += RUN) {
+        h = hash32(h + 0x9e3779b9u);
+        const uint32_t node = h % 405u;
+#pragma unroll
+        for (int c = 0; c < RUN; ++c) atomicAdd(&img[node * 8 + (RUN == 8 ? c : (h >> 16) & 7)], 1.0f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3240; i += 256) out[(int64_t)(blockIdx.x & 1023) * 3240 + i] = img[i];
+}
+
 // gathers only, table by table without the 64-bit division of S1: blockIdx.y = n
 __global__ __launch_bounds__(256) void quad_gather_n(const float4 *table, int64_t nodes_per_n, int W, int64_t P, float *out) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -264,6 +283,8 @@ int main() {
         TIME("A4 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 128 B aligned", (atomic_rows<32, 32><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 22) - 1, R / 4)));
         TIME("A6 2^24 64-B row atomics, each workgroup's 256 rows inside one random 16 KiB window", (atomic_rows_local<<<(R / 2) / 256, 256>>>(acc, (1u << 15) - 1, 16)));
         TIME("A7 2^24 64-B row atomics, 64 rows per workgroup and window (4x as many workgroups)", (atomic_rows_local<<<(R / 2) / 64, 256>>>(acc, (1u << 15) - 1, 4)));
+        TIME("L1 2^28 LDS float atomics, random floats of a 13 KiB image, 65536 workgroups x 256 threads x 16", (lds_atomics<1><<<65536, 256>>>(acc, 16)));
+        TIME("L2 2^28 LDS float atomics, runs of 8 consecutive floats (node rows)", (lds_atomics<8><<<65536, 256>>>(acc, 16)));
         TIME("A5 2^23 row atomics, 32 lanes x 4 B = 128 B rows, 32 B aligned", (atomic_rows<32, 8><<<(R / 4) * 32 / 256, 256>>>(acc, (1u << 24) - 4, R / 4)));
     }
     return 0;
