@@ -355,6 +355,8 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.chunks = L.chunks;
     p.chunk = L.chunk;
     p.dense = L.dense;
+    p.scell = nullptr;
+    p.ntz = 1;
     return p;
 }
 
@@ -659,6 +661,8 @@ tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
     p.chunks = L.chunks;
     p.chunk = L.chunk;
     p.dense = 1;
+    p.scell = nullptr;
+    p.ntz = 1;
     return p;
 }
 int build_plan3(const Problem &pb, const float *grid, const float *offset, void *blob) {
@@ -681,6 +685,83 @@ int build_plan3(const Problem &pb, const float *grid, const float *offset, void 
     cs::dense3::plan_scatter3<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
     return launch_status();
 }
+// 3D tables too large for the cell histogram (cs_dense3d.cuh, tiles3): grad_input cut into 16x4x4-node tiles, every sample
+// listed in the tiles that own its corners, one wave per tile sums its list without atomics and writes the tile out
+namespace t3 = cs::tiles3;
+struct Tiles3Dims { int64_t ntx, nty, ntz, ntiles; };
+Tiles3Dims tiles3_dims(int64_t D, int64_t H, int64_t W) {
+    Tiles3Dims t;
+    t.ntx = (W + t3::M3X - 1) / t3::M3X;
+    t.nty = (H + t3::M3Y - 1) / t3::M3Y;
+    t.ntz = (D + t3::M3Z - 1) / t3::M3Z;
+    t.ntiles = t.ntx * t.nty * t.ntz;
+    return t;
+}
+constexpr int64_t kTiles3MinSamples = 1 << 18;
+constexpr int64_t kTiles3MaxLists = 8;   // a sample is listed at most once per corner
+bool tiles3_applies(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
+    const int mode = g_force_path.load(std::memory_order_relaxed);
+    if (mode == 1 || mode == 3) return false;              // testing: direct kernels / row atomics only
+    if (dense3_applies(N, C, D, H, W, P)) return false;    // crowded tables: a wave per cell
+    const Tiles3Dims t = tiles3_dims(D, H, W);
+    if (C > 16 || t.ntiles > 12288 || N * t.ntiles >= (int64_t)INT32_MAX) return false;   // tile histogram in 48 KiB of LDS
+    // keys are (p << 9) | code; list positions are 32-bit
+    if (P >= ((int64_t)1 << 23) || N * P * kTiles3MaxLists >= (int64_t)0xFFFFFFF0ll || N > 65535) return false;
+    return mode >= 2 || N * P >= kTiles3MinSamples;
+}
+struct Plan3TLayout {
+    Tiles3Dims t;
+    int chunks, chunk;
+    size_t off_key, off_tile_begin, off_block_hist, off_totals, off_bsum, bytes;
+};
+Plan3TLayout plan3t_layout(int64_t N, int64_t D, int64_t H, int64_t W, int64_t P) {
+    Plan3TLayout L;
+    L.t = tiles3_dims(D, H, W);
+    L.chunk = plan_chunk(N, P, (int)L.t.ntiles);
+    L.chunks = (int)((P + L.chunk - 1) / L.chunk);
+    const size_t E = (size_t)N * P * kTiles3MaxLists;   // list entries, worst case (1.66 per sample at 16x4x4 nodes)
+    size_t o = 0;
+    L.off_key = o;        o += align256(E * 4);
+    L.off_tile_begin = o; o += align256(((size_t)N * L.t.ntiles + 1) * 4);
+    L.off_block_hist = o; o += align256((size_t)N * L.chunks * L.t.ntiles * 4);
+    L.off_totals = o;     o += align256((size_t)N * L.t.ntiles * 4);
+    L.off_bsum = o;       o += align256(((size_t)N * L.t.ntiles / 1024 + 3) * 4);
+    L.bytes = o;
+    return L;
+}
+tl::Plan plan3t_view(const Plan3TLayout &L, void *blob) {
+    char *b = (char *)blob;
+    tl::Plan p;
+    p.sorted = nullptr;
+    p.key = (uint32_t *)(b + L.off_key);      // the lists themselves: (p << 9) | code, grouped by tile
+    p.cellb = nullptr;
+    p.scell = nullptr;
+    p.Gs = nullptr;
+    p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
+    p.cell_begin = nullptr;
+    p.block_hist = (uint32_t *)(b + L.off_block_hist);
+    p.ntx = (int)L.t.ntx;
+    p.nty = (int)L.t.nty;
+    p.ntz = (int)L.t.ntz;
+    p.ntiles = (int)L.t.ntiles;
+    p.chunks = L.chunks;
+    p.chunk = L.chunk;
+    p.dense = 0;
+    return p;
+}
+int build_plan3t(const Problem &pb, const float *grid, const float *offset, void *blob) {
+    Plan3TLayout L = plan3t_layout(pb.d.N, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
+    tl::Plan pl = plan3t_view(L, blob);
+    uint32_t *totals = (uint32_t *)((char *)blob + L.off_totals);
+    dim3 g((unsigned)L.chunks, (unsigned)pb.d.N);
+    const size_t shm = (size_t)pl.ntiles * 4;
+    t3::plan_count3t<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    const int64_t nt = (int64_t)pb.d.N * pl.ntiles;
+    tl::plan_scan_chunks<<<(unsigned)((nt + 255) / 256), 256, 0, pb.stream>>>(pl, pb.d.N, totals);
+    scan_buckets(totals, pl.tile_begin, (uint32_t *)((char *)blob + L.off_bsum), nt, pb.stream);
+    t3::plan_scatter3t<<<g, 256, shm, pb.stream>>>(grid, offset, pl, pb.d, pb.f);
+    return launch_status();
+}
 // floats per p-ordered row of the 3D dense path: cl::Rec without the node ids
 int dense3_row_floats(int64_t C, int stage) { return (int)((cpad(C) + 8) * (stage == CS_STAGE_BBB_FUSED ? 2 : 1)); }
 
@@ -698,6 +779,16 @@ size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, i
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     if (!have_plan) need += align256(plan3_layout(N, D, H, W, P).bytes);
+    return need + align256((size_t)N * P * dense3_row_floats(C, stage) * 4);
+}
+
+size_t tiles3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int have_cl,
+                        int have_plan, int have_cI) {
+    size_t T = align256((size_t)N * cpad(C) * D * H * W * 4), need = 0;
+    if (!have_cl) need += T;
+    if (stage == CS_STAGE_FORWARD) return need;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    if (!have_plan) need += align256(plan3t_layout(N, D, H, W, P).bytes);
     return need + align256((size_t)N * P * dense3_row_floats(C, stage) * 4);
 }
 
@@ -763,6 +854,40 @@ int dense3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, flo
     return launch_status();
 }
 
+// 3D tile path: plan (caller's or built into the workspace), p-ordered rows
+int tiles3_prepare(const Problem &pb, const float *grid, const float *offset, const void *plan, Carve &ws, int stage,
+                   tl::Plan &pl, float *&rows) {
+    Plan3TLayout L = plan3t_layout(pb.d.N, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
+    if (plan) {
+        pl = plan3t_view(L, const_cast<void *>(plan));
+    } else {
+        void *blob = ws.take(L.bytes);
+        if (!ws.ok()) return CS_ERR_WORKSPACE;
+        int rc = build_plan3t(pb, grid, offset, blob);
+        if (rc) return rc;
+        pl = plan3t_view(L, blob);
+    }
+    rows = (float *)ws.take((size_t)pb.d.S * dense3_row_floats(pb.d.C, stage) * 4);
+    return ws.ok() ? CS_OK : CS_ERR_WORKSPACE;
+}
+template <int MODE>
+int tiles3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, float *grad_input) {
+    const int CP = (int)cpad(pb.d.C);
+    const int waves = CP <= 8 ? 4 : 2;                                   // 4 / 8 / 16 KiB of LDS image per wave
+    const size_t shm = (size_t)waves * t3::OWNED * CP * 4;
+    const int64_t nb = (int64_t)pb.d.N * pl.ntiles;
+    CS_DISPATCH_CQ(pb.d.C, (t3::tile3_scatter<CQ, MODE><<<(unsigned)((nb + waves - 1) / waves), 64 * waves, shm, pb.stream>>>(
+                               rows, pl, grad_input, pb.d, waves)));
+    return launch_status();
+}
+// which scatter a 3D stage with grad_input uses: 0 fused row atomics, 1 wave per cell (crowded), 2 wave per tile (no atomics)
+template <int DIM>
+int scatter3_way(const Problem &pb) {
+    if (DIM != 3) return 0;
+    if (dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P)) return 1;
+    return tiles3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P) ? 2 : 0;
+}
+
 template <int DIM>
 int rcl_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
                  float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
@@ -777,18 +902,19 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
         return launch_status();
     }
     const size_t shm = rcl_lds<DIM>(pb.d.C, 0);
-    if (DIM == 3 && dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P)) {
+    if (const int way = scatter3_way<DIM>(pb)) {
         tl::Plan pl;
         float *rows;
-        rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD, pl, rows);
+        rc = way == 1 ? dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD, pl, rows)
+                      : tiles3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD, pl, rows);
         if (rc) return rc;
-        rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (way == 1) rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
                                           (const ST *)gOut, icl, grid, offset, grad_grid, rows, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
-        return dense3_scatter<0>(pb, pl, rows, grad_input);
+        return way == 1 ? dense3_scatter<0>(pb, pl, rows, grad_input) : tiles3_scatter<0>(pb, pl, rows, grad_input);
     }
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
@@ -816,14 +942,17 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
         if (rc) return rc;
         cIcl = buf;
     }
-    const bool dense = gInput && DIM == 3 &&
-                       dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P);
-    float *acc = nullptr;     // channels-last accumulator (row atomics) or the p-ordered rows (dense)
+    const int way = gInput ? scatter3_way<DIM>(pb) : 0;
+    const bool dense = way != 0;   // the point kernel leaves p-ordered rows (SCATTER == 2)
+    float *acc = nullptr;     // channels-last accumulator (row atomics) or the p-ordered rows (dense / tiles)
     tl::Plan pl;
-    if (dense) {
+    if (way == 1) {
         rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD_BACKWARD, pl, acc);
         if (rc) return rc;
         rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (rc) return rc;
+    } else if (way == 2) {
+        rc = tiles3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BACKWARD_BACKWARD, pl, acc);
         if (rc) return rc;
     } else if (gInput) {
         rc = rcl_accumulator(pb, ws, acc);
@@ -842,7 +971,8 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
 #undef CS_RCL_BB
     rc = launch_status();
     if (rc || !gInput) return rc;
-    if (dense) return dense3_scatter<1>(pb, pl, acc, gInput);
+    if (way == 1) return dense3_scatter<1>(pb, pl, acc, gInput);
+    if (way == 2) return tiles3_scatter<1>(pb, pl, acc, gInput);
     return rcl_finish(pb, acc, gInput);
 }
 
@@ -855,18 +985,19 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
     int rc = rows_cl_table(pb, input, input_cl, ws, icl);
     if (rc) return rc;
     const size_t shm = rcl_lds<DIM>(pb.d.C, 2);
-    if (DIM == 3 && dense3_applies(pb.d.N, pb.d.C, pb.d.size[2], pb.d.size[1], pb.d.size[0], pb.d.P)) {
+    if (const int way = scatter3_way<DIM>(pb)) {
         tl::Plan pl;
         float *rows;
-        rc = dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BBB_FUSED, pl, rows);
+        rc = way == 1 ? dense3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BBB_FUSED, pl, rows)
+                      : tiles3_prepare(pb, grid, offset, plan, ws, CS_STAGE_BBB_FUSED, pl, rows);
         if (rc) return rc;
-        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        if (way == 1) rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
                                           icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, rows, pb.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
-        return dense3_scatter<2>(pb, pl, rows, gInput);
+        return way == 1 ? dense3_scatter<2>(pb, pl, rows, gInput) : tiles3_scatter<2>(pb, pl, rows, gInput);
     }
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
@@ -937,6 +1068,7 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (rows_cl_applies(dim, N, C, P, vol)) {
         if (dense3_applies(N, C, D, H, W, P)) return dense3_workspace(stage, N, C, D, H, W, P, have_input_cl, have_plan, have_cI);
+        if (tiles3_applies(N, C, D, H, W, P)) return tiles3_workspace(stage, N, C, D, H, W, P, have_input_cl, have_plan, have_cI);
         return rows_cl_workspace(stage, N, C, vol, have_input_cl, have_cI);
     }
     if (stage != CS_STAGE_FORWARD && rows_applies(N, C, P, vol)) return align256((size_t)N * C * vol * 4);
@@ -986,8 +1118,9 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
 
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (!rows_cl_applies(3, N, C, P, D * H * W) || !dense3_applies(N, C, D, H, W, P)) return 0;
-    return plan3_layout(N, D, H, W, P).bytes;
+    if (!rows_cl_applies(3, N, C, P, D * H * W)) return 0;
+    if (dense3_applies(N, C, D, H, W, P)) return plan3_layout(N, D, H, W, P).bytes;
+    return tiles3_applies(N, C, D, H, W, P) ? plan3t_layout(N, D, H, W, P).bytes : 0;
 }
 
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes, int64_t N, int64_t C,
@@ -997,10 +1130,12 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
     if (flags & ~CS_GRID_BROADCAST) return CS_ERR_INVALID;
     int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, flags, multicell, stream);
     if (rc) return rc;
-    if (!rows_cl_applies(3, N, C, P, D * H * W) || !dense3_applies(N, C, D, H, W, P)) return CS_ERR_UNSUPPORTED;
+    if (!rows_cl_applies(3, N, C, P, D * H * W)) return CS_ERR_UNSUPPORTED;
+    const bool dense = dense3_applies(N, C, D, H, W, P);
+    if (!dense && !tiles3_applies(N, C, D, H, W, P)) return CS_ERR_UNSUPPORTED;
     if (!grid || !offset || !plan) return CS_ERR_INVALID;
-    if (plan_bytes < plan3_layout(N, D, H, W, P).bytes) return CS_ERR_WORKSPACE;
-    return build_plan3(pb, grid, offset, plan);
+    if (plan_bytes < (dense ? plan3_layout(N, D, H, W, P).bytes : plan3t_layout(N, D, H, W, P).bytes)) return CS_ERR_WORKSPACE;
+    return dense ? build_plan3(pb, grid, offset, plan) : build_plan3t(pb, grid, offset, plan);
 }
 
 #define CS_PROBLEM(dim, D)                                                                                        \

@@ -162,4 +162,229 @@ __global__ __launch_bounds__(256) void cell_scatter3(const float *__restrict__ r
 }
 
 }  // namespace dense3
+
+// ------------------------------------------------------------------------------------------------------------------
+// tiles3 -- large, sparsely hit 3D tables (BASELINE configs[3]: 128^3 nodes, 0.25 samples per cell) WITHOUT atomics.
+// The fused row atomics of cs_points_cl.cuh sit on a floor that ordering cannot move: 2^24 pair-row atomics take
+// 0.83 ms wherever they land, and LDS float atomics are slower still (profiles/round2_microbench_atomics.txt).  So:
+//   plan    grad_input is cut into tiles of 16x4x4 NODES, each owned by one wave.  A sample is listed in every tile that
+//           owns one of its 8 corner nodes (1.66 tiles on average), with a 9-bit code = where its low corner sits
+//           relative to that tile (-1..15, -1..3, -1..3); the 2D plan's scan kernels, no order inside a bucket
+//   points  the channels-last point kernels leave p-ordered rows [cotangents | coefficients] (SCATTER == 2, as for the
+//           crowded tables above)
+//   tile3_scatter   a wave sums its tile in an LDS image, list entries taken 64 at a time.  Entries with DIFFERENT
+//           codes never meet at a node in the same round (a round = one corner); entries with the same code are
+//           ranked inside the batch and rank r is added in pass r -- plain LDS read-modify-writes,
+//           wave-synchronous, no atomics -- and corners owned by another tile are skipped (that tile lists the sample
+//           too).  The tile then leaves for grad_input in the caller's NCDHW layout with plain 64-byte row stores:
+//           every node of every tile exactly once, so no accumulator, no clear, no unpack.
+// (A first version with cell tiles, one list entry per sample and 9x9x5-node images summed by a second kernel moved
+// 3 GB per stage through those images and took 0.72 ms for the two kernels.)
+// ------------------------------------------------------------------------------------------------------------------
+namespace tiles3 {
+
+using tiled::Plan;
+constexpr int M3X = 16, M3Y = 4, M3Z = 4, OWNED = M3X * M3Y * M3Z;        // nodes per tile
+constexpr int K3X = M3X + 1, K3Y = M3Y + 1, K3Z = M3Z + 1;               // code range per axis: low corner slot + 1
+constexpr int BINS = 512;                                                // codes take 9 bits: K3X * K3Y * K3Z = 425
+static_assert(K3X * K3Y * K3Z <= BINS, "a code fits 9 bits");
+
+// the low corner of a sample per axis, lo in [-1, size-1]; valid = it touches at least one node of the table
+struct Low3 {
+    int lo[3];
+    bool valid;
+};
+__device__ __forceinline__ Low3 locate3m(const float *g, const Dims &d, const Flags &f, float off) {
+    Low3 q;
+    q.valid = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float mu;
+        float i = source_index(g[j], d.size[j], f.pad, f.align, off, f.multicell, mu);
+        bool sane = (i > -1073741824.0f) && (i < 1073741824.0f);
+        q.lo[j] = sane ? (int)floorf(i) : -4;
+        q.valid = q.valid && q.lo[j] >= -1 && q.lo[j] <= d.size[j] - 1;
+    }
+    return q;
+}
+// calls emit(tile, code) for every tile that owns a corner node of the sample
+template <typename F>
+__device__ __forceinline__ void for_each_tile(const Low3 &q, const Dims &d, const Plan &pl, F emit) {
+    int t[3][2], cnt[3];
+    constexpr int M[3] = {M3X, M3Y, M3Z};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int a = q.lo[j] >= 0 ? q.lo[j] / M[j] : -1;                          // tile of node lo (if it exists)
+        const int b = q.lo[j] + 1 <= d.size[j] - 1 ? (q.lo[j] + 1) / M[j] : -1;    // tile of node lo + 1
+        cnt[j] = 0;
+        if (a >= 0) t[j][cnt[j]++] = a;
+        if (b >= 0 && b != a) t[j][cnt[j]++] = b;
+    }
+    for (int kz = 0; kz < cnt[2]; ++kz)
+        for (int ky = 0; ky < cnt[1]; ++ky)
+            for (int kx = 0; kx < cnt[0]; ++kx) {
+                const int tx = t[0][kx], ty = t[1][ky], tz = t[2][kz];
+                const int cx = q.lo[0] - tx * M3X + 1, cy = q.lo[1] - ty * M3Y + 1, cz = q.lo[2] - tz * M3Z + 1;
+                emit((tz * pl.nty + ty) * pl.ntx + tx, (cz * K3Y + cy) * K3X + cx);
+            }
+}
+
+// (chunks, N) workgroups: histogram of the tile lists of one chunk of one n
+__global__ __launch_bounds__(256) void plan_count3t(const float *__restrict__ grid, const float *__restrict__ offset,
+                                                    Plan pl, Dims d, Flags f) {
+    extern __shared__ uint32_t hist[];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    for (int b = threadIdx.x; b < pl.ntiles; b += 256) hist[b] = 0;
+    __syncthreads();
+    const float off = offset[n];
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
+        int64_t p = p0 + i;
+        if (p < d.P) {
+            Low3 q = locate3m(grid + d.gpt(n, p) * 3, d, f, off);
+            if (q.valid) for_each_tile(q, d, pl, [&](int tile, int) { atomicAdd(&hist[tile], 1u); });
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = pl.block_hist + ((int64_t)n * pl.chunks + chunk) * pl.ntiles;
+    for (int b = threadIdx.x; b < pl.ntiles; b += 256) dst[b] = hist[b];
+}
+// (chunks, N): every list entry takes a slot of its tile's bucket (any order); key = (p << 9) | code
+__global__ __launch_bounds__(256) void plan_scatter3t(const float *__restrict__ grid, const float *__restrict__ offset,
+                                                      Plan pl, Dims d, Flags f) {
+    extern __shared__ uint32_t cursor[];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const uint32_t *excl = pl.block_hist + ((int64_t)n * pl.chunks + chunk) * pl.ntiles;
+    const uint32_t *tb = pl.tile_begin + (int64_t)n * pl.ntiles;
+    for (int b = threadIdx.x; b < pl.ntiles; b += 256) cursor[b] = tb[b] + excl[b];
+    __syncthreads();
+    const float off = offset[n];
+    const int64_t p0 = (int64_t)chunk * pl.chunk;
+    for (int i = threadIdx.x; i < pl.chunk; i += 256) {
+        int64_t p = p0 + i;
+        if (p < d.P) {
+            Low3 q = locate3m(grid + d.gpt(n, p) * 3, d, f, off);
+            if (q.valid)
+                for_each_tile(q, d, pl, [&](int tile, int code) {
+                    pl.key[atomicAdd(&cursor[tile], 1u)] = ((uint32_t)p << 9) | (uint32_t)code;
+                });
+        }
+    }
+}
+// One wave per (n, tile) bucket; blockDim = 64 * waves, dynamic LDS = waves * OWNED * CQ float4 (4 / 8 / 16 KiB per wave:
+// the CU fills with waves, which is what hides the chain  bucket bounds -> ids -> rows -> LDS -> output  of a tile; a
+// version that took four tiles per wave and fetched the next tile's first batch ahead was no faster).
+template <int CQ, int MODE>
+struct Batch3 {   // one lane's share of a batch: a sample's row
+    using R = cl::Rec<3, CQ, MODE>;
+    float4 g[CQ], h[CQ], ka[2], kb[2];
+    __device__ __forceinline__ void load(const float *rows, uint32_t id) {
+        const float *row = rows + (int64_t)id * R::IDS;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            g[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+            if (MODE == 2) h[q] = *reinterpret_cast<const float4 *>(row + 4 * CQ + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ka[q] = *reinterpret_cast<const float4 *>(row + R::COEF + 4 * q);
+            if (MODE == 2) kb[q] = *reinterpret_cast<const float4 *>(row + R::COEF + 8 + 4 * q);
+        }
+    }
+};
+// add one batch (lane = list entry) to the wave's image [z][y][x][CQ]
+template <int CQ, int MODE>
+__device__ __forceinline__ void sum_batch3(float4 *img, const Batch3<CQ, MODE> &b, int code, bool live) {
+    const int lane = threadIdx.x & 63;
+    // rank of this entry among the entries of the batch with the same code (the bucket is in no particular order: 64
+    // lane reads and compares cost less than sorting every bucket in the plan did -- 0.16 ms per step at config 3)
+    const int mycode = live ? code : -1 - lane;
+    int rank = 0;
+#pragma unroll
+    for (int l = 0; l < 63; ++l) rank += (l < lane && __builtin_amdgcn_readlane(mycode, l) == mycode) ? 1 : 0;
+    int maxrank = rank;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) maxrank = max(maxrank, __shfl_xor(maxrank, m));
+    const int cx = code % K3X, cyz = code / K3X, cy = cyz % K3Y, cz = cyz / K3Y;
+    const int sx = cx - 1, sy = cy - 1, sz = cz - 1;             // slot of the low corner inside the tile, -1 .. M-1
+    const float ca[8] = {b.ka[0].x, b.ka[0].y, b.ka[0].z, b.ka[0].w, b.ka[1].x, b.ka[1].y, b.ka[1].z, b.ka[1].w};
+    float cb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (MODE == 2) { cb[0] = b.kb[0].x; cb[1] = b.kb[0].y; cb[2] = b.kb[0].z; cb[3] = b.kb[0].w; cb[4] = b.kb[1].x; cb[5] = b.kb[1].y; cb[6] = b.kb[1].z; cb[7] = b.kb[1].w; }
+    for (int r = 0; r <= maxrank; ++r) {
+        if (live && rank == r) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {      // a round = one corner: different codes -> different nodes
+                const int x = sx + (a & 1), y = sy + ((a >> 1) & 1), z = sz + (a >> 2);
+                if (x >= 0 && x < M3X && y >= 0 && y < M3Y && z >= 0 && z < M3Z) {   // else: another tile's node
+                    float4 *node = img + ((z * M3Y + y) * M3X + x) * CQ;
+#pragma unroll
+                    for (int q = 0; q < CQ; ++q) {
+                        float4 t = cl::fma4(ca[a], b.g[q], node[q]);
+                        if (MODE == 2) t = cl::fma4(cb[a], b.h[q], t);
+                        node[q] = t;
+                    }
+                }
+                // The next round's nodes are other LANES' nodes of this round (code c's high-x corner is code c+1's
+                // low-x one).  One thread's own addresses differ by constants, so without this the compiler batches
+                // the eight reads ahead of the eight writes; the hardware needs nothing (LDS runs a wave in order).
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ranks of one code follow each other
+    }
+}
+template <int CQ, int MODE>
+__global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ rows, Plan pl, float *__restrict__ out,
+                                                     Dims d, int waves) {
+    constexpr int CP = 4 * CQ;
+    extern __shared__ float4 img_all[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t bucket = (int64_t)blockIdx.x * waves + wv;
+    if (bucket >= (int64_t)d.N * pl.ntiles) return;
+    float4 *img = img_all + wv * (OWNED * CQ);     // this wave's image: LDS operations of ONE wave execute in order,
+                                                   // so no barrier is needed anywhere below
+    const uint32_t b0 = pl.tile_begin[bucket], b1 = pl.tile_begin[bucket + 1];
+    const uint32_t sbase = (uint32_t)(bucket / pl.ntiles) * (uint32_t)d.P;          // n * P
+    for (int i = lane; i < OWNED * CQ; i += 64) img[i] = cl::zero4();
+    for (uint32_t j0 = b0; j0 < b1; j0 += 128) {   // two entries per lane: a tile lists ~100 at config 3
+        const bool liveA = j0 + lane < b1, liveB = j0 + 64 + lane < b1;
+        const uint32_t jA = liveA ? j0 + lane : b1 - 1, jB = liveB ? j0 + 64 + lane : b1 - 1;
+        const uint32_t kA = pl.key[jA], kB = pl.key[jB];                            // (p << 9) | code
+        const int codeA = (int)(kA & (BINS - 1)), codeB = (int)(kB & (BINS - 1));
+        Batch3<CQ, MODE> A, B;
+        A.load(rows, sbase + (kA >> 9));
+        B.load(rows, sbase + (kB >> 9));
+        sum_batch3<CQ, MODE>(img, A, codeA, liveA);
+        if (j0 + 64 < b1) sum_batch3<CQ, MODE>(img, B, codeB, liveB);
+    }
+    // the tile leaves: rows of 16 nodes along x of one (channel, z, y), 64 contiguous bytes each
+    const int W = d.size[0], H = d.size[1], D = d.size[2];
+    const int n = (int)(bucket / pl.ntiles);
+    int tl = (int)(bucket - (int64_t)n * pl.ntiles);
+    const int tx = tl % pl.ntx;
+    tl /= pl.ntx;
+    const int ty = tl % pl.nty, tz = tl / pl.nty;
+    const int x0 = tx * M3X, y0 = ty * M3Y, z0 = tz * M3Z;
+    const float *imf = reinterpret_cast<const float *>(img);
+    float *o = out + (int64_t)n * d.C * d.vol;
+    const bool vec = (W & 3) == 0;
+    for (int i = lane; i < CP * M3Z * M3Y * (M3X / 4); i += 64) {     // one float4 of x per item
+        const int x4 = i % (M3X / 4), r = i / (M3X / 4), y = r % M3Y, zc = r / M3Y, z = zc % M3Z, c = zc / M3Z;
+        const int gx = x0 + 4 * x4, gy = y0 + y, gz = z0 + z;
+        if (c >= d.C || gy >= H || gz >= D || gx >= W) continue;
+        const float *src = imf + (((z * M3Y + y) * M3X + 4 * x4) * CQ) * 4 + c;     // channel c of 4 nodes
+        const float4 v = make_float4(src[0], src[CP], src[2 * CP], src[3 * CP]);
+        float *dst = o + (int64_t)c * d.vol + ((int64_t)gz * H + gy) * W + gx;
+        if (vec) {
+            *reinterpret_cast<float4 *>(dst) = v;                     // W % 4 == 0: whole quads are in range
+        } else {
+            dst[0] = v.x;
+            if (gx + 1 < W) dst[1] = v.y;
+            if (gx + 2 < W) dst[2] = v.z;
+            if (gx + 3 < W) dst[3] = v.w;
+        }
+    }
+}
+
+}  // namespace tiles3
 }  // namespace cs

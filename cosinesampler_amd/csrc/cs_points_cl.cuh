@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, con
         g[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
         gather_quad<DIM, CQ>(tab, sm, q, v[q]);
     }
+    // every gather in flight before the first one is consumed: left alone, the scheduler issued the second quad's node
+    // rows two at a time between the uses of the first (four more HBM round trips per wave; 3D config 3: 0.73 -> ms)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < CQ; ++q)
 #pragma unroll
@@ -237,12 +240,18 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
-        float4 g = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
+        gq[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
+        gather_quad<DIM, CQ>(tab, sm, q, vq[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const float4 g = gq[q];
         if (SCATTER) *reinterpret_cast<float4 *>(rec + 4 * q) = g;
-        float4 v[NC];
-        gather_quad<DIM, CQ>(tab, sm, q, v);
+        const float4(&v)[NC] = vq[q];
         float4 o = zero4();
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fma4(Dm[a], v[a], o);

@@ -54,12 +54,20 @@ def test_loader_binds_and_reports_errors_without_gpu():
     assert lib.cs_workspace_bytes(3, 1 | 0x10, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == 0
     # a crowded table (96 tables of 16x16 cells, 10^5 points) keeps round 1's path: one fat row per sample
     assert lib.cs_workspace_bytes(2, 1, 96, 4, 1, 16, 16, 100000, 1, 1, 0) == 96 * 100000 * 32
-    # 3D and other power-of-two channel counts: row-atomic scatter into a channels-last scratch of
-    # input's size (backward stages only); odd channel counts and tiny sample counts need nothing
+    # 3D, BASELINE configs[3] (not crowded): the tile path -- a plan (the per-tile sample lists) and p-ordered rows of
+    # 8 + 8 floats, no accumulator
     T3 = 8 * 8 * 128 ** 3 * 4
-    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == T3      # the accumulator
-    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == 2 * T3  # + channels-last copy
+    S3 = 8 << 19
+    plan3 = lib.cs3d_plan_bytes(8, 8, 128, 128, 128, 1 << 19)
+    assert plan3 > S3 * 8 * 4                                                               # 8 list slots per sample
+    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 1, 1, 0) == S3 * 64
+    assert lib.cs_workspace_bytes(3, 3, 8, 8, 128, 128, 128, 1 << 19, 1, 1, 0) == S3 * 128  # fused third backward: two payloads
+    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == T3 + plan3 + S3 * 64
     assert lib.cs_workspace_bytes(3, 0, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == 0
+    # a table too large for the tile histogram keeps the row atomics: an accumulator of input's size
+    T4 = 2 * 4 * 512 * 512 * 256 * 4
+    assert lib.cs3d_plan_bytes(2, 4, 256, 512, 512, 1 << 20) == 0
+    assert lib.cs_workspace_bytes(3, 1, 2, 4, 256, 512, 512, 1 << 20, 1, 0, 0) == T4
     assert lib.cs_pack_bytes(3, 8, 8, 128, 128, 128, 1 << 19) == T3
     assert lib.cs_workspace_bytes(2, 3, 16, 64, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 64 * 256 * 256 * 4
     # 5 channels run zero-padded as 8 on the tiled path: table copy (8 ch), plan, rows of 8 + 4 floats

@@ -175,6 +175,41 @@ def test_row_scatter_path_matches_cpu_oracle(d, C, ke, pad, align, mc, shared, f
         assert_close(got[k], want[k], "rows d=%d C=%d kernel=%d pad=%d align=%s mc=%s: %s" % (d, C, ke, pad, align, mc, k))
 
 
+TILES3_CASES = [   # C, (W, H, D) as sp = (D, H, W) below, P, kernel, pad, align, multicell
+    (8, (20, 9, 37), 30000, 2, 0, True, True),      # the config-3 kind: sparse, several tiles per axis, W % 4 != 0
+    (8, (16, 16, 32), 3000, 0, 0, True, True),      # W % 4 == 0: float4 row stores; ~0.3 samples per cell
+    (3, (7, 21, 18), 20000, 0, 1, False, False),    # one zero-padded quad, border padding, align_corners = False
+    (16, (12, 6, 40), 25000, 2, 2, True, False),    # 4 quads (two waves per workgroup), reflection
+    (5, (33, 5, 17), 20000, 1, 0, True, True),      # padded to 8, linear kernel
+    (4, (4, 4, 16), 2500, 0, 0, True, True),        # a single tile per (y, z), crowded: many entries with the same code
+    (1, (9, 3, 5), 300, 2, 0, False, True),         # tiny
+]
+
+
+@pytest.mark.parametrize("C,dims,P,ke,pad,align,mc", TILES3_CASES)
+@pytest.mark.parametrize("shared", [False, True])
+def test_tiles3_path_matches_cpu_oracle(C, dims, P, ke, pad, align, mc, shared):
+    """3D tables that are not crowded enough for the wave-per-cell path: grad_input cut into 16x4x4-node tiles, every
+    sample listed in the tiles that own its corners, one wave per tile, no atomics (cs_dense3d.cuh tiles3).  Partial
+    tiles at every face, widths that are and are not multiples of 4, every quad count, all paddings."""
+    N = 3
+    sp = dims
+    D, H, W = sp
+    t = _case(3, N, C, sp, P, seed=3300 + C + P, spread=1.15)
+    off = offsets(N, mc)
+    want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
+    lib = _lib.load()
+    ops.force_path(2)
+    try:
+        assert lib.cs3d_plan_bytes(N, C, D, H, W, P) > 0 and P < 8 * (D + 1) * (H + 1) * (W + 1)   # a plan, and not the cell one
+        got = _run_all_stages(_Shared() if shared else ops, t, off, pad, align, ke, mc, DEV)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for k in want:
+        assert_close(got[k], want[k], "tiles3 C=%d %s P=%d kernel=%d pad=%d align=%s mc=%s: %s" % (C, sp, P, ke, pad, align, mc, k))
+
+
 @pytest.mark.parametrize("d,C,force", [(2, 16, 2), (2, 4, 2), (2, 3, 0), (2, 32, 2), (3, 8, 2), (3, 3, 0), (3, 2, 2)])
 @pytest.mark.parametrize("with_cI", [False, True])
 def test_second_backward_without_table_gradient(d, C, force, with_cI):

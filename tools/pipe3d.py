@@ -17,6 +17,9 @@ for step in range(int(os.environ.get("CS_STEPS", "5"))):
     sc = ops.StepContext()
     ops.forward(c3, g3, o3, 0, True, 2, True, ctx=sc)
     ops.backward(go3, c3, g3, o3, 0, True, True, 2, True, ctx=sc)
+    if os.environ.get("CS_EXTRA", "1") == "1":      # the same stages without the table gradient: point kernels alone
+        ops.backward(go3, c3, g3, o3, 0, True, False, 2, True, ctx=sc)
+        ops.backward_backward(None, cg3, c3, g3, go3, o3, 0, True, False, 2, True, ctx=sc, want_grad_input=False)
     ops.backward_backward(None, cg3, c3, g3, go3, o3, 0, True, False, 2, True, ctx=sc)
     ops.bbb_fused(c3, g3, go3, cg3, hg3, ho3, o3, 0, True, 2, True, ctx=sc)
 torch.cuda.synchronize()
