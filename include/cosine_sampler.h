@@ -134,8 +134,10 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
                     void *stream);
 
-/* The same for 3D, where a plan exists only for small crowded tables (cells = (D+1)(H+1)(W+1) <= 40000, C <= 16 (run zero-padded to 4, 8 or 16 channels),
- * P >= 8 cells: the reference's test_3d.py shapes): samples binned by cell.  cs3d_plan_bytes returns 0 otherwise. */
+/* The same for 3D (C <= 16, run zero-padded to 4, 8 or 16 channels).  Two kinds of plan, chosen by the sizes: small
+ * crowded tables (cells = (D+1)(H+1)(W+1) <= 40000 and P >= 8 cells: the reference's test_3d.py shapes) -- samples binned
+ * by cell; other tables of up to 12288 tiles of 16x4x4 nodes, P < 2^23 per table (BASELINE configs[3]) -- every sample
+ * listed in the tiles that own its corner nodes.  cs3d_plan_bytes returns 0 where neither applies (row atomics). */
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t plan_bytes,
                     int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
