@@ -211,9 +211,25 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     if (!SCATTER && !live) return;
     if (SCATTER) rec_put_nodes<DIM, CQ, 1>(rec, sm, d, live);
     if (live) {
+    // loads first, all of them (see bbb): grad_out_grid through a pointer that is valid either way, the cotangent quads, the
+    // node rows; the coefficient tables are worked out while they fly
+    const float *cgp = (cG ? cG : grid) + d.gpt(sm.n, sm.p) * DIM;
     float cg[DIM];
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cG[d.gpt(sm.n, sm.p) * DIM + j] : 0.0f;
+    for (int j = 0; j < DIM; ++j) cg[j] = cgp[j];
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
+    const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        gq[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
+        gather_quad<DIM, CQ>(tab, sm, q, vq[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) cg[j] = cG ? cg[j] : 0.0f;
     float W[NC], Dm[NC], F[DIM][NC], Sg[DIM][NC];
     sm.weights(W);
 #pragma unroll
@@ -236,17 +252,6 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     float acc[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
-    const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
-    float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        gq[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
-        gather_quad<DIM, CQ>(tab, sm, q, vq[q]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         const float4 g = gq[q];
@@ -310,14 +315,39 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
     if (!SCATTER && !live) return;
     if (SCATTER) rec_put_nodes<DIM, CQ, 2>(rec, sm, d, live);
     if (live) {
+    // every load of the sample goes out before anything is computed from it: the cotangents of the grid (read through a
+    // pointer that is valid either way and masked afterwards -- a load inside `p ? *p : 0` is waited for on its own),
+    // the stream quads, then the node rows
+    const int64_t o0 = d.gpt(sm.n, sm.p) * DIM;
+    const float *cgp = cG ? cG + o0 : grid + o0, *hgp = hG ? hG + o0 : grid + o0;
+    float cgv[DIM], hgv[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        cgv[j] = cgp[j];
+        hgv[j] = hgp[j];
+    }
+    float4 gq[CQ], hq[CQ];
+    if (SCATTER) {
+        const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            gq[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
+            hq[q] = zero4();
+            if (hO) hq[q] = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
+        }
+    }
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    float4 v[CQ][NC];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
+    __builtin_amdgcn_sched_barrier(0);
     float Em[NC], Dm[NC];
 #pragma unroll
     for (int a = 0; a < NC; ++a) Em[a] = Dm[a] = 0.0f;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        int64_t o = d.gpt(sm.n, sm.p) * DIM + j;
-        float cgj = cG ? cG[o] : 0.0f;
-        float hgj = hG ? hG[o] : 0.0f;
+        const float cgj = cG ? cgv[j] : 0.0f;
+        const float hgj = hG ? hgv[j] : 0.0f;
         float e = cgj * hgj;
 #pragma unroll
         for (int a = 0; a < NC; ++a) {
@@ -328,20 +358,17 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
 #pragma unroll
             for (int k = 0; k < DIM; ++k) {
                 if (k == j) continue;
-                float ek = hgj * (cG ? cG[o - j + k] : 0.0f);
+                float ek = hgj * (cG ? cgv[k] : 0.0f);
 #pragma unroll
                 for (int a = 0; a < NC; ++a) Em[a] = fmaf(sm.mixed2(a, j, k), ek, Em[a]);
             }
         }
     }
     if (SCATTER) {   // cotangent streams and coefficients of the scatter: E_a * gOut + D_a * hO
-        const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
-            *reinterpret_cast<float4 *>(rec + 4 * q) = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
-            float4 h = zero4();
-            if (hO) h = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
-            *reinterpret_cast<float4 *>(rec + C + 4 * q) = h;
+            *reinterpret_cast<float4 *>(rec + 4 * q) = gq[q];
+            *reinterpret_cast<float4 *>(rec + C + 4 * q) = hq[q];
         }
 #pragma unroll
         for (int a = 0; a < NC; ++a) {
@@ -349,11 +376,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
             rec[R::COEF + NC + a] = Dm[a];
         }
     }
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
-    float4 v[CQ][NC];
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 o = zero4();
