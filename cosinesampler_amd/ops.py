@@ -200,6 +200,18 @@ class StepContext(object):
         return self._plan
 
 
+    def prepare_plan(self, input, grid, offset, padding_mode, align_corners, multicell):
+        """Build the point plan of `grid` now, on the current stream (otherwise the first stage that scatters builds it).
+        -> True if this problem has a plan.  Lets a caller account for the plan separately from the stage that happens to
+        need it first: it depends on the grid alone and serves every backward stage of the step."""
+        dim, shape, P = _problem(input, grid)
+        _offset_ok(offset, shape[0], input.device)
+        lib = _lib.load()
+        with torch.cuda.device(input.device):
+            stream = torch.cuda.current_stream(input.device).cuda_stream
+            return self.plan(lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream) is not None
+
+
 _force_epoch = 0
 
 

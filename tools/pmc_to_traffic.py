@@ -55,13 +55,14 @@ plan = ["cs::tiled::plan_count", "cs::tiled::plan_scan_chunks", "cs::tiled::plan
         "cs::tiled::plan_tile_sort"]
 stages = {
     "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4, float>"],
-    "backward": plan + ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
+    "plan": plan,   # built once per step, used by the three backward stages (bench.py times it as its own span)
+    "backward": ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
     "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
     "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2, float>"],
-    "3d_backward": ["cs::tiles3::plan_count3t", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiles3::plan_scatter3t",
-                    "cs::cl::backward<3, 2, 2, 2, float>", "cs::tiles3::tile3_scatter<2, 0>"],
+    "3d_plan": ["cs::tiles3::plan_count3t", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiles3::plan_scatter3t"],
+    "3d_backward": ["cs::cl::backward<3, 2, 2, 2, float>", "cs::tiles3::tile3_scatter<2, 0>"],
     "3d_backward_backward": ["cs::cl::backward_backward<3, 2, 2, false, 2, float>", "cs::tiles3::tile3_scatter<2, 1>"],
     "3d_bbb_fused": ["cs::cl::bbb<3, 2, 2, 2, float>", "cs::tiles3::tile3_scatter<2, 2>"],
 }
