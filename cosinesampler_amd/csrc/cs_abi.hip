@@ -355,8 +355,6 @@ tl::Plan plan_view(const PlanLayout &L, void *blob) {
     p.chunks = L.chunks;
     p.chunk = L.chunk;
     p.dense = L.dense;
-    p.scell = nullptr;
-    p.ntz = 1;
     return p;
 }
 
@@ -661,8 +659,6 @@ tl::Plan plan3_view(const Plan3Layout &L, void *blob) {
     p.chunks = L.chunks;
     p.chunk = L.chunk;
     p.dense = 1;
-    p.scell = nullptr;
-    p.ntz = 1;
     return p;
 }
 int build_plan3(const Problem &pb, const float *grid, const float *offset, void *blob) {
@@ -735,14 +731,12 @@ tl::Plan plan3t_view(const Plan3TLayout &L, void *blob) {
     p.sorted = nullptr;
     p.key = (uint32_t *)(b + L.off_key);      // the lists themselves: (p << 9) | code, grouped by tile
     p.cellb = nullptr;
-    p.scell = nullptr;
     p.Gs = nullptr;
     p.tile_begin = (uint32_t *)(b + L.off_tile_begin);
     p.cell_begin = nullptr;
     p.block_hist = (uint32_t *)(b + L.off_block_hist);
     p.ntx = (int)L.t.ntx;
     p.nty = (int)L.t.nty;
-    p.ntz = (int)L.t.ntz;
     p.ntiles = (int)L.t.ntiles;
     p.chunks = L.chunks;
     p.chunk = L.chunk;

@@ -63,8 +63,6 @@ struct Plan {
                            // by plan_scatter directly, no per-tile pass, no cell_begin; consumed by cell_scatter
     float *Gs;             // [S*CP] (walker plans only) grad_output rows in SORTED order, channels-last: left by the
                            // first tile kernel that fetched them by sample id, streamed by the later stages' walkers
-    uint8_t *scell;        // unused (kept so that the struct's layout is the one the 3D views initialise)
-    int ntz;               // 3D tile plans: tiles along z (ntiles = ntx * nty * ntz)
 };
 
 struct Geo2 {  // tile coordinates of a sample; u = lo + 1 so that lo = -1 (only the high node valid) is cell 0
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     __shared__ uint32_t scan[CELLS];
     const int64_t t = blockIdx.x;
     const uint32_t b0 = pl.tile_begin[t], b1 = pl.tile_begin[t + 1];
-    uint32_t *cbeg = pl.cell_begin ? pl.cell_begin + t * (CELLS + 1) : nullptr;   // (3D tile plans keep `scell` instead)
+    uint32_t *cbeg = pl.cell_begin + t * (CELLS + 1);
     cnt[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) atomicAdd(&cnt[pl.cellb ? pl.cellb[j] : (pl.key[j] & 0xFFu)], 1u);
@@ -253,10 +251,8 @@ __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     }
     uint32_t start = scan[threadIdx.x] - v;   // exclusive start of each cell, also the running cursor
     cnt[threadIdx.x] = start;
-    if (cbeg) {
-        cbeg[threadIdx.x] = start;
-        if (threadIdx.x == CELLS - 1) cbeg[CELLS] = b1 - b0;
-    }
+    cbeg[threadIdx.x] = start;
+    if (threadIdx.x == CELLS - 1) cbeg[CELLS] = b1 - b0;
     __syncthreads();
     const uint32_t sbase = (uint32_t)(t / pl.ntiles) * (uint32_t)P;   // n * P
     for (uint32_t j = b0 + threadIdx.x; j < b1; j += 256) {
