@@ -21,11 +21,14 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = random.Random(seed)
 
 
-def rel(a, b):
+SCALE = {}
+
+
+def rel(a, b, scale=0.0):
     a, b = a.double().cpu(), b.double().cpu()
     # inputs are O(1): an output whose largest entry is far below that (a handful of points at the edge of the table)
     # is compared on the scale of the data, not of its own cancellation (seed 7 case 394: 2 points, max|out| 3e-3)
-    den = max(float(b.abs().max()), 0.05)
+    den = max(float(b.abs().max()), 0.05, scale)
     return float((a - b).abs().max()) / den
 
 
@@ -60,7 +63,8 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
     r["fI"], r["fO"] = mod.bbb_fused(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], off, pad, align, ke, mc, **kw)
     if bc and mod is cs_oracle:
         for k in GRID_RESULTS:
-            r[k] = r[k].sum(0, keepdim=True)
+            SCALE[k] = float(r[k].abs().max())     # the summands' magnitude: a sum over n may cancel (case 544 of seed 77:
+            r[k] = r[k].sum(0, keepdim=True)       # terms of +-12 summing to 0.06), its error is that of the terms
     return r
 
 
@@ -76,9 +80,11 @@ for case in range(cases):
     force = rng.choice([0, 1, 2, 2, 2, 3, 4])
     shared = rng.choice([True, False])
     bc = N > 1 and rng.random() < 0.25
+    spread = rng.choice([0.9, 1.0, 1.3])
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
+        continue                      # (every random draw of the case is above: case k is the same problem as in a full run)
     g = torch.Generator().manual_seed(seed * 100003 + case)
     inp = torch.rand((N, C) + sp, generator=g)
-    spread = rng.choice([0.9, 1.0, 1.3])
     grid = torch.rand((N,) + (1,) * (d - 1) + (P, d), generator=g) * (2 * spread) - spread
     if P >= 3:
         grid.view(N, P, d)[:, 0] = -1.0
@@ -87,6 +93,7 @@ for case in range(cases):
     t = dict(inp=inp, grid=grid, gOut=torch.randn(osh, generator=g), cI=torch.randn(inp.shape, generator=g),
              cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g), hO=torch.randn(osh, generator=g))
     off = multicell_offset(N, mc, "cpu")
+    SCALE.clear()
     want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc)
     ops.force_path(force)
     try:
@@ -94,7 +101,13 @@ for case in range(cases):
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)
-    errs = {k: rel(got[k], want[k]) for k in want}
+    errs = {k: rel(got[k], want[k], SCALE.get(k, 0.0)) for k in want}
+    if os.environ.get("FUZZ_ONLY") or os.environ.get("FUZZ_DETAIL") == str(case):
+        for k in want:
+            print(k, "%.3e" % errs[k], "max|ref| %.4g" % float(want[k].abs().max()), flush=True)
+        w = max(errs, key=errs.get)
+        print("got ", got[w].flatten()[:12].tolist())
+        print("want", want[w].flatten()[:12].tolist())
     worst = max(errs, key=errs.get)
     if not all(torch.isfinite(v).all() for v in got.values()) or errs[worst] > 1e-5:
         bad += 1
