@@ -645,19 +645,25 @@ def test_tiled_path_crowded_tables(C, P, pad, mode):
         assert_close(got[k], want[k], "crowded C=%d P=%d pad=%d: %s" % (C, P, pad, k))
 
 
-@pytest.mark.parametrize("shape", [(4, 16, 48, 30000), (96, 4, 16, 40000), (2, 3, 20, 3000), (3, 32, 40, 30000)])
+@pytest.mark.parametrize("shape", [(4, 16, 48, 30000), (96, 4, 16, 40000), (2, 3, 20, 3000), (3, 32, 40, 30000),
+                                   (4, 8, (12, 20, 36), 70000), (6, 4, (8, 8, 8), 60000)])
 def test_stages_can_be_captured_in_a_hip_graph(shape):
     """Nothing in a stage allocates through HIP, synchronises or touches the host, so a whole
     step -- channels-last copy, plan, forward and the three backward stages -- can be captured into a HIP graph and
-    replayed on new data in the same buffers (what a launch-bound PIXEL loop wants).  Tiled, crowded and direct paths."""
+    replayed on new data in the same buffers (what a launch-bound PIXEL loop wants).  Tiled, crowded and direct paths in
+    2D; in 3D (a tuple of sizes) the tile path and the wave-per-cell path."""
     N, C, S, P = shape
+    sp = S if isinstance(S, tuple) else (S, S)
+    dm = len(sp)
+    gshape = (N,) + (1,) * (dm - 1) + (P, dm)
+    oshape = (N, C) + (1,) * (dm - 1) + (P,)
     g = torch.Generator().manual_seed(77)
-    cells = torch.rand(N, C, S, S, generator=g).to(DEV)
-    grid = (torch.rand(N, 1, P, 2, generator=g) * 2.2 - 1.1).to(DEV)
-    gO = torch.randn(N, C, 1, P, generator=g).to(DEV)
-    cG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
-    hG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
-    hO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    cells = torch.rand((N, C) + sp, generator=g).to(DEV)
+    grid = (torch.rand(gshape, generator=g) * 2.2 - 1.1).to(DEV)
+    gO = torch.randn(oshape, generator=g).to(DEV)
+    cG = torch.randn(gshape, generator=g).to(DEV)
+    hG = torch.randn(gshape, generator=g).to(DEV)
+    hO = torch.randn(oshape, generator=g).to(DEV)
     off = offsets(N, True).to(DEV)
 
     def step():
@@ -674,9 +680,9 @@ def test_stages_can_be_captured_in_a_hip_graph(shape):
     with torch.cuda.graph(graph):
         captured = step()
     for trial in range(2):                   # new data in the captured input buffers
-        cells.copy_(torch.rand(N, C, S, S, generator=g))
-        grid.copy_(torch.rand(N, 1, P, 2, generator=g) * 2.2 - 1.1)
-        gO.copy_(torch.randn(N, C, 1, P, generator=g))
+        cells.copy_(torch.rand((N, C) + sp, generator=g))
+        grid.copy_(torch.rand(gshape, generator=g) * 2.2 - 1.1)
+        gO.copy_(torch.randn(oshape, generator=g))
         graph.replay()
         torch.cuda.synchronize()
         got = [t.clone() for t in captured]
