@@ -147,14 +147,6 @@ __global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, con
     if (!SCATTER && !live) return;
     if (SCATTER) rec_put_nodes<DIM, CQ, 0>(rec, sm, d, live);
     if (live) {
-    float oth[DIM][NC];
-#pragma unroll
-    for (int j = 0; j < DIM; ++j)
-#pragma unroll
-        for (int a = 0; a < NC; ++a) oth[j][a] = ((a >> j) & 1) ? sm.others(a, j) : -sm.others(a, j);
-    float acc[DIM];
-#pragma unroll
-    for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float4 v[CQ][NC], g[CQ];
@@ -164,8 +156,16 @@ __global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, con
         gather_quad<DIM, CQ>(tab, sm, q, v[q]);
     }
     // every gather in flight before the first one is consumed: left alone, the scheduler issued the second quad's node
-    // rows two at a time between the uses of the first (four more HBM round trips per wave; 3D config 3: 0.73 -> ms)
+    // rows two at a time between the uses of the first (four more HBM round trips per wave; 3D config 3: 0.72 -> 0.54 ms)
     __builtin_amdgcn_sched_barrier(0);
+    float oth[DIM][NC];   // (worked out while the rows fly: fewer registers live across the wait)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int a = 0; a < NC; ++a) oth[j][a] = ((a >> j) & 1) ? sm.others(a, j) : -sm.others(a, j);
+    float acc[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) acc[j] = 0.0f;
 #pragma unroll
     for (int q = 0; q < CQ; ++q)
 #pragma unroll

@@ -11,9 +11,12 @@
 //     (tools/microbench_sum.hip O1-O5): a kernel costs t_gather + bytes / 6.5 TB/s, so gathers are issued with as
 //     little register footprint as possible (C/4 lanes per sample) and streams are kept to the algorithmic bytes
 //     plus the fat rows;
-//   * random reads are charged per 64-byte sector: an 80-byte fat row costs 1.6 sectors on average.
+//   * every read that misses the L2 moves a 128-byte line (round 2 counters: TCC_EA0_RDREQ_128B = all requests): an
+//     80-byte row fetched by id costs 1.5 lines on average, a 16-byte record a whole one; random line reads run at
+//     6.9 TB/s, random 64-byte writes at 3 TB/s -- so records are WRITTEN in p-order and FETCHED by id, never the reverse.
 //
-// Structure of one backward stage (grad_input part):
+// Structure of one backward stage (grad_input part; round 2: the first scatter stage of a step also leaves grad_output in
+// cell order inside the plan -- Plan::Gs -- and the later stages write only their coefficients):
 //   plan   (once per grid)  sort the samples by (n, 16x16-cell tile, cell): `sorted[j]` = sample id
 //                           at sorted position j, first position of every tile (`tile_begin`) and
 //                           of every cell in it (`cell_begin`).
