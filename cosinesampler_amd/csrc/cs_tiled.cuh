@@ -413,12 +413,18 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
     ST *obase = out + (int64_t)n * d.C * d.P;   // d.C: the caller's channel count (template C is the padded one)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
+    QuadSample qsv[CQ];
+    float4 vv[CQ][4];
+#pragma unroll
+    for (int sub = 0; sub < CQ; ++sub) {   // every pass's node rows in flight before the first is blended
+        qsv[sub].read(rec, sub, CQ, d);
+        gather4<CQ>(tab, qsv[sub], vv[sub]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
-        QuadSample qs;
-        qs.read(rec, sub, CQ, d);
-        float4 v[4];
-        gather4<CQ>(tab, qs, v);
+        const QuadSample &qs = qsv[sub];
+        const float4(&v)[4] = vv[sub];
         float4 acc = zero4();
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc = fma4(qs.W[a], v[a], acc);
@@ -702,6 +708,7 @@ __global__ __launch_bounds__(256) void point_backward(const ST *__restrict__ gOu
     float4 vv[CQ][4];
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    __builtin_amdgcn_sched_barrier(0);   // every pass's gathers issued before anything consumes one
     if (WANT_ROWS) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
@@ -777,6 +784,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
     float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    __builtin_amdgcn_sched_barrier(0);   // every pass's gathers issued before anything consumes one
     if (ROWS == 1) flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
@@ -858,6 +866,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
     float4 vv[CQ][4];   // every pass's gathers are issued before any result is written (LDS writes would fence them)
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) q_gather<CQ>(tab, rec, sub * (64 / CQ) + lane / CQ, q, vv[sub]);
+    __builtin_amdgcn_sched_barrier(0);   // every pass's gathers issued before anything consumes one
     flush_rows<STRIDE>(stage, fat, sm.n, d);   // while the gathers are in flight
 #pragma unroll
     for (int sub = 0; sub < CQ; ++sub) {
