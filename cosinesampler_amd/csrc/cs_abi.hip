@@ -373,20 +373,24 @@ int build_plan(const Problem &pb, const float *grid, const float *offset, void *
     return launch_status();
 }
 
-int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipStream_t s) {
+// plane > 0: the z-paired layout of the 3D tables (two rows per node, see cs::pack_cl4), plane = H * W
+int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipStream_t s, int64_t plane = 0) {
     if (N == 0 || C == 0 || vol == 0) return CS_OK;
     const int64_t CP = cpad(C);
-    if ((vol & 3) == 0 && CP <= 64 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {   // 16-byte accesses on both sides
-        const int nv = cs::cl4_nv((int)CP);
-        const size_t shm = cs::cl4_lds((int)CP);
+    const int slots = plane > 0 ? 2 : 1;
+    if ((vol & 3) == 0 && (plane & 3) == 0 && CP <= 64 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {   // 16-byte accesses on both sides
+        const int nv = cs::cl4_nv((int)CP) / slots;                 // both slots of a node leave from one workgroup
+        const size_t shm = (size_t)slots * CP * (nv + 4) * 4;
         dim3 g((unsigned)((vol + nv - 1) / nv), (unsigned)N);
-        cs::pack_cl4<<<g, 256, shm, s>>>(in, out, (int)C, (int)CP, vol);
+        cs::pack_cl4<<<g, 256, shm, s>>>(in, out, (int)C, (int)CP, vol, plane, slots);
         return launch_status();
     }
-    dim3 g((unsigned)((vol + 63) / 64), (unsigned)N);
-    tl::pack_channels_last<<<g, 256, (size_t)CP * 65 * 4, s>>>(in, out, (int)C, (int)CP, vol);
+    dim3 g((unsigned)((vol + 63) / 64), (unsigned)N, (unsigned)slots);
+    tl::pack_channels_last<<<g, 256, (size_t)CP * 65 * 4, s>>>(in, out, (int)C, (int)CP, vol, plane, slots);
     return launch_status();
 }
+// floats of a channels-last table copy: 3D tables are z-paired
+size_t table_floats(int dim, int64_t N, int64_t C, int64_t vol) { return (size_t)N * cpad(C) * vol * (dim == 3 ? 2 : 1); }
 
 // carve the workspace in the order cs_workspace_bytes adds it up: [input_cl?][plan?][gOutInput channels-last?][fat rows | accumulator]
 struct Carve {
@@ -607,7 +611,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
 bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     const int mode = g_force_path.load(std::memory_order_relaxed);
     if (mode == 1 || dim != 3 || C > 16) return false;   // other counts run zero-padded to 4, 8 or 16 (cpad)
-    if (N * P >= ((int64_t)1 << 31) || N * vol >= ((int64_t)1 << 31) || vol * cpad(C) >= ((int64_t)1 << 31)) return false;
+    if (N * P >= ((int64_t)1 << 31) || N * vol >= ((int64_t)1 << 31) || vol * cpad(C) >= ((int64_t)1 << 30)) return false;   // (the table copy holds two rows per node)
     if (N > 65535) return false;                               // pack / unpack launch with gridDim.y = N
     return mode >= 2 || N * P >= (1 << 16);   // (global node ids of the fused scatter are 32-bit)
 }
@@ -759,16 +763,17 @@ int build_plan3t(const Problem &pb, const float *grid, const float *offset, void
 // floats per p-ordered row of the 3D dense path: cl::Rec without the node ids
 int dense3_row_floats(int64_t C, int stage) { return (int)((cpad(C) + 8) * (stage == CS_STAGE_BBB_FUSED ? 2 : 1)); }
 
+// (these three are 3D paths: a channels-last TABLE copy is z-paired, twice the accumulator's size)
 size_t rows_cl_workspace(int stage, int64_t N, int64_t C, int64_t vol, int have_cl, int have_cI) {
-    size_t T = align256((size_t)N * cpad(C) * vol * 4), need = 0;
-    if (!have_cl) need += T;
+    size_t T = align256((size_t)N * cpad(C) * vol * 4), T2 = align256(table_floats(3, N, C, vol) * 4), need = 0;
+    if (!have_cl) need += T2;
     if (stage == CS_STAGE_FORWARD) return need;
-    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
+    if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T2;
     return need + T;   // + the channels-last accumulator of row_scatter
 }
 size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int have_cl,
                         int have_plan, int have_cI) {
-    size_t T = align256((size_t)N * cpad(C) * D * H * W * 4), need = 0;
+    size_t T = align256(table_floats(3, N, C, D * H * W) * 4), need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
@@ -778,7 +783,7 @@ size_t dense3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, i
 
 size_t tiles3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int have_cl,
                         int have_plan, int have_cI) {
-    size_t T = align256((size_t)N * cpad(C) * D * H * W * 4), need = 0;
+    size_t T = align256(table_floats(3, N, C, D * H * W) * 4), need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
@@ -789,10 +794,10 @@ size_t tiles3_workspace(int stage, int64_t N, int64_t C, int64_t D, int64_t H, i
 // resolve the channels-last table (caller's or packed into the workspace)
 int rows_cl_table(const Problem &pb, const float *input, const float *input_cl, Carve &ws, const float *&icl) {
     if (input_cl) { icl = input_cl; return CS_OK; }
-    float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
+    float *buf = (float *)ws.take(table_floats(3, pb.d.N, pb.d.C, pb.d.vol) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     icl = buf;
-    return pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+    return pack_cl(input, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream, (int64_t)pb.d.size[0] * pb.d.size[1]);
 }
 
 template <int DIM>
@@ -930,9 +935,9 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
-        float *buf = (float *)ws.take((size_t)pb.d.N * cpad(pb.d.C) * pb.d.vol * 4);
+        float *buf = (float *)ws.take(table_floats(DIM, pb.d.N, pb.d.C, pb.d.vol) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
-        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
+        rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream, DIM == 3 ? (int64_t)pb.d.size[0] * pb.d.size[1] : 0);
         if (rc) return rc;
         cIcl = buf;
     }
@@ -1079,7 +1084,7 @@ size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (!tiled_applies(dim, N, C, H, W, P) && !rows_cl_applies(dim, N, C, P, vol)) return 0;
-    return align256((size_t)N * cpad(C) * vol * 4);
+    return align256(table_floats(dim, N, C, vol) * 4);
 }
 
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
@@ -1088,7 +1093,7 @@ int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64
     if (N < 0 || C < 0 || D < 1 || H < 1 || W < 1) return CS_ERR_INVALID;
     if (N * C > 0 && (!input || !input_cl)) return CS_ERR_INVALID;
     if (cpad(C) * 65 * 4 > 64 * 1024) return CS_ERR_UNSUPPORTED;
-    return pack_cl(input, input_cl, N, C, (dim == 3 ? D : 1) * H * W, (hipStream_t)stream);
+    return pack_cl(input, input_cl, N, C, (dim == 3 ? D : 1) * H * W, (hipStream_t)stream, dim == 3 ? H * W : 0);
 }
 
 size_t cs2d_plan_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {

@@ -43,11 +43,19 @@ __device__ __forceinline__ void store_quad(T *dst, int64_t P, float4 o, int cv) 
     if (cv > 3) stream_store(dst + 3 * P, o.w);
 }
 
-// node rows of one channel quad; zero-padded nodes read row 0 and are masked
+// node rows of one channel quad; zero-padded nodes read row 0 and are masked.
+// 3D tables are z-paired (pack_cl4: node v holds [its own row | the row of the node one z-plane above]): a corner on the
+// sample's upper z-plane is read from the second slot of the node below it whenever that node's plane exists, so that the
+// four rows (x, x+1) x (z, z+1) of one y are one contiguous run of 4 * C floats.  `plane` = H * W.
 template <int DIM, int CQ>
-__device__ __forceinline__ void gather_quad(const float4 *tab, const Sample<DIM> &sm, int q, float4 (&v)[1 << DIM]) {
+__device__ __forceinline__ void gather_quad(const float4 *tab, const Sample<DIM> &sm, int q, float4 (&v)[1 << DIM],
+                                            int64_t plane = 0) {
 #pragma unroll
-    for (int a = 0; a < (1 << DIM); ++a) v[a] = tab[(sm.node[a] < 0 ? 0 : sm.node[a]) * CQ + q];
+    for (int a = 0; a < (1 << DIM); ++a) {
+        int64_t row = sm.node[a] < 0 ? 0 : sm.node[a];
+        if (DIM == 3) row = ((a & 4) && sm.ax[DIM - 1].lo >= 0 && sm.node[a] >= 0) ? (row - plane) * 2 + 1 : row * 2;
+        v[a] = tab[row * CQ + q];
+    }
 #pragma unroll
     for (int a = 0; a < (1 << DIM); ++a)
         if (sm.node[a] < 0) v[a] = zero4();
@@ -118,11 +126,12 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     if (!sm.template load<KERNEL, 0>(grid, offset, d, f, DIM == 2 ? 1 : f.align)) return;
     float W[NC];
     sm.weights(W);
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     ST *o = out + (int64_t)sm.n * d.C * d.P + sm.p;   // d.C: the caller's channel count (C is the padded one)
     float4 v[CQ][NC];
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
+    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 acc = zero4();
@@ -147,13 +156,14 @@ __global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, con
     if (!SCATTER && !live) return;
     if (SCATTER) rec_put_nodes<DIM, CQ, 0>(rec, sm, d, live);
     if (live) {
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     float4 v[CQ][NC], g[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         g[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
-        gather_quad<DIM, CQ>(tab, sm, q, v[q]);
+        gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
     }
     // every gather in flight before the first one is consumed: left alone, the scheduler issued the second quad's node
     // rows two at a time between the uses of the first (four more HBM round trips per wave; 3D config 3: 0.72 -> 0.54 ms)
@@ -217,15 +227,16 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     float cg[DIM];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) cg[j] = cgp[j];
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
-    const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C);
+    const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
+    const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
     float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         gq[q] = load_quad(go + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
-        gather_quad<DIM, CQ>(tab, sm, q, vq[q]);
+        gather_quad<DIM, CQ>(tab, sm, q, vq[q], plane);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
         }
         if (HAS_CI) {
             float4 u[NC];
-            gather_quad<DIM, CQ>(ctab, sm, q, u);
+            gather_quad<DIM, CQ>(ctab, sm, q, u, plane);
 #pragma unroll
             for (int a = 0; a < NC; ++a) o = fma4(W[a], u[a], o);
             if (FULL) {
@@ -336,10 +347,11 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
             if (hO) hq[q] = load_quad(hO + (int64_t)sm.n * d.ho_ns + sm.p + (int64_t)(4 * q) * d.P, d.P, d.C - 4 * q);
         }
     }
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C);
+    const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
+    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     float4 v[CQ][NC];
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q]);
+    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
     __builtin_amdgcn_sched_barrier(0);
     float Em[NC], Dm[NC];
 #pragma unroll

@@ -94,16 +94,17 @@ __device__ __forceinline__ Geo2 locate(float gx, float gy, const Dims &d, const 
 // ------------------------------------------------------------------------------------------------
 // channels-last repack:  in (N,C,vol) -> out (N,vol,CP), CP = C rounded up to a multiple of 4 (extra channels zero)
 // ------------------------------------------------------------------------------------------------
+// (shift, slots: the z-paired 3D layout, see pack_cl4 in cs_kernels_direct.cuh; 0, 1 otherwise)
 __global__ __launch_bounds__(256) void pack_channels_last(const float *__restrict__ in, float *__restrict__ out,
-                                                          int C, int CP, int64_t vol) {
+                                                          int C, int CP, int64_t vol, int64_t shift, int slots) {
     extern __shared__ float tile[];  // [CP][65]
-    const int n = blockIdx.y;
-    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int n = blockIdx.y, slot = blockIdx.z;
+    const int64_t v0 = (int64_t)blockIdx.x * 64, src0 = v0 + slot * shift;
     const int CQ = CP >> 2;
     for (int idx = threadIdx.x; idx < CP * 64; idx += 256) {
         int c = idx >> 6, v = idx & 63;
         float x = 0.0f;
-        if (c < C && v0 + v < vol) x = in[((int64_t)n * C + c) * vol + v0 + v];
+        if (c < C && src0 + v < vol) x = in[((int64_t)n * C + c) * vol + src0 + v];
         tile[c * 65 + v] = x;
     }
     __syncthreads();
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void pack_channels_last(const float *__restric
         if (v0 + v < vol) {
             float4 r = make_float4(tile[(4 * q) * 65 + v], tile[(4 * q + 1) * 65 + v], tile[(4 * q + 2) * 65 + v],
                                    tile[(4 * q + 3) * 65 + v]);
-            *reinterpret_cast<float4 *>(out + (((int64_t)n * vol + v0 + v) * CP + 4 * q)) = r;
+            *reinterpret_cast<float4 *>(out + ((((int64_t)n * vol + v0 + v) * slots + slot) * CP + 4 * q)) = r;
         }
     }
 }

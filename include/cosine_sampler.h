@@ -117,9 +117,11 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
 /* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
 int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 
-/* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C rounded up to a multiple of 4 (the extra
- * channels are zero: 2D tables with 1..3 channels run as one float4 quad).  Returns the byte size of the copy / makes
- * it.  cs_pack_bytes returns 0 when no fast path applies. */
+/* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C padded with zero channels to 4, 8, 16 or 32
+ * (2D tables with 1..3 channels run as one float4 quad).  In 3D the copy is z-paired -- every node carries its own row and
+ * the row of the node one z-plane above, twice the bytes -- so that the 2x2 rows a sample needs per y are contiguous.
+ * Returns the byte size of the copy / makes it; an opaque object for the stage calls' `input_cl`.  cs_pack_bytes returns 0
+ * when no fast path applies. */
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 int cs_pack_input(int dim, const float *input, float *input_cl, int64_t N, int64_t C, int64_t D, int64_t H,
                   int64_t W, void *stream);

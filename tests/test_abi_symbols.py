@@ -62,13 +62,13 @@ def test_loader_binds_and_reports_errors_without_gpu():
     assert plan3 > S3 * 8 * 4                                                               # 8 list slots per sample
     assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 1, 1, 0) == S3 * 64
     assert lib.cs_workspace_bytes(3, 3, 8, 8, 128, 128, 128, 1 << 19, 1, 1, 0) == S3 * 128  # fused third backward: two payloads
-    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == T3 + plan3 + S3 * 64
+    assert lib.cs_workspace_bytes(3, 1, 8, 8, 128, 128, 128, 1 << 19, 0, 0, 0) == 2 * T3 + plan3 + S3 * 64   # the 3D table copy is z-paired
     assert lib.cs_workspace_bytes(3, 0, 8, 8, 128, 128, 128, 1 << 19, 1, 0, 0) == 0
     # a table too large for the tile histogram keeps the row atomics: an accumulator of input's size
     T4 = 2 * 4 * 512 * 512 * 256 * 4
     assert lib.cs3d_plan_bytes(2, 4, 256, 512, 512, 1 << 20) == 0
     assert lib.cs_workspace_bytes(3, 1, 2, 4, 256, 512, 512, 1 << 20, 1, 0, 0) == T4
-    assert lib.cs_pack_bytes(3, 8, 8, 128, 128, 128, 1 << 19) == T3
+    assert lib.cs_pack_bytes(3, 8, 8, 128, 128, 128, 1 << 19) == 2 * T3
     assert lib.cs_workspace_bytes(2, 3, 16, 64, 1, 256, 256, 1 << 20, 0, 0, 0) == 16 * 64 * 256 * 256 * 4
     # 5 channels run zero-padded as 8 on the tiled path: table copy (8 ch), plan, rows of 8 + 4 floats
     assert lib.cs_workspace_bytes(2, 1, 16, 5, 1, 256, 256, 1 << 20, 0, 0, 0) == (
