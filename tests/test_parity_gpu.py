@@ -948,6 +948,47 @@ def test_full_size_2d_properties(N, C, H, P):
         assert rel_err(got, ref) <= 1e-5, "shared StepContext vs independent calls: %s" % nm
 
 
+def test_full_size_extensions():
+    """BASELINE configs[1] sizes (N=16 C=16 256^2 P=2^20) for the two opt-in input forms: one set of points for every
+    table (CS_GRID_BROADCAST) against the repeated grid, and bfloat16 streams against the fp32 op -- same kernels as the
+    headline step, so same numbers: per-sample outputs bit for bit, sums to rounding."""
+    N, C, H, P = 16, 16, 256, 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(99)
+    cells = torch.rand(N, C, H, H, generator=g).to(DEV)
+    pts = (torch.rand(1, 1, P, 2, generator=g) * 2.1 - 1.05).to(DEV)
+    gridN = pts.repeat(N, 1, 1, 1)
+    gO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    cG1 = torch.randn(1, 1, P, 2, generator=g).to(DEV)
+    hG1 = torch.randn(1, 1, P, 2, generator=g).to(DEV)
+    hO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    off = offsets(N, True).to(DEV)
+    a, b = ops.StepContext(), ops.StepContext()
+    out1 = ops.forward(cells, pts, off, 0, True, 0, True, ctx=a)
+    outN = ops.forward(cells, gridN, off, 0, True, 0, True, ctx=b)
+    assert torch.equal(out1, outN)
+    gI1, gG1 = ops.backward(gO, cells, pts, off, 0, True, True, 0, True, ctx=a)
+    gIN, gGN = ops.backward(gO, cells, gridN, off, 0, True, True, 0, True, ctx=b)
+    assert gG1.shape == pts.shape
+    assert_close(gI1, gIN, "full size, broadcast grid: grad_input", tol=2e-6)
+    assert_close(gG1, gGN.sum(0, keepdim=True), "full size, broadcast grid: grad_grid", tol=2e-6)
+    t1 = ops.bbb_fused(cells, pts, gO, cG1, hG1, hO, off, 0, True, 0, True, ctx=a)
+    tN = ops.bbb_fused(cells, gridN, gO, cG1.repeat(N, 1, 1, 1), hG1.repeat(N, 1, 1, 1), hO, off, 0, True, 0, True, ctx=b)
+    assert torch.equal(t1[1], tN[1])
+    assert_close(t1[0], tN[0], "full size, broadcast grid: third-backward grad_input", tol=2e-6)
+    del a, b, gridN, tN, gIN, gGN
+    torch.cuda.empty_cache()
+    # bfloat16 streams: the forward rounds the same fp32 sums once; the cotangent is read as bfloat16 exactly
+    assert ops.half_streams_ok(cells, pts)
+    out16 = ops.forward(cells, pts, off, 0, True, 0, True, out_dtype=torch.bfloat16)
+    assert torch.equal(out16, out1.to(torch.bfloat16))
+    gO16 = gO.to(torch.bfloat16)
+    gI16, gG16 = ops.backward(gO16, cells, pts, off, 0, True, True, 0, True)
+    gI32, gG32 = ops.backward(gO16.float(), cells, pts, off, 0, True, True, 0, True)
+    assert_close(gI16, gI32, "full size, bfloat16 cotangent: grad_input", tol=2e-6)
+    assert_close(gG16, gG32, "full size, bfloat16 cotangent: grad_grid", tol=2e-6)
+    torch.cuda.synchronize()
+
+
 def test_full_size_3d_properties():
     # BASELINE.json configs[3]: 3D smoothstep, N=8 C=8 128^3, P=2^19
     torch.manual_seed(1)
