@@ -11,6 +11,7 @@
 #include "cs_points_cl.cuh"
 #include "cs_tiled.cuh"
 #include "cs_dense3d.cuh"
+#include "cs_units.h"
 
 namespace {
 
@@ -27,6 +28,7 @@ struct Problem {
     int dim;
     int kernel;
     int sdt;      // element type of the channel-major streams: 0 fp32, 1 half, 2 bfloat16 (CS_STREAM_*)
+    bool coherent;   // CS_POINTS_COHERENT: the caller says consecutive points share cells
     hipStream_t stream;
     unsigned blocks;
 };
@@ -38,7 +40,8 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     if ((kernel & CS_STREAM_F16) && (kernel & CS_STREAM_BF16)) return CS_ERR_INVALID;
     pb.sdt = (kernel & CS_STREAM_F16) ? 1 : (kernel & CS_STREAM_BF16) ? 2 : 0;
     const bool grid_bc = (kernel & CS_GRID_BROADCAST) != 0;
-    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST);
+    pb.coherent = (kernel & CS_POINTS_COHERENT) != 0;
+    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST | CS_POINTS_COHERENT);
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
     // node indices and sizes are kept in 32-bit registers; element offsets are 64-bit
     if (N > INT32_MAX || C > INT32_MAX || D > (1 << 28) || H > (1 << 28) || W > (1 << 28)) return CS_ERR_UNSUPPORTED;
@@ -405,13 +408,15 @@ struct Carve {
 };
 
 size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
-                       int have_cI) {
+                       int have_cI, bool coherent) {
     const int64_t CP = cpad(C);
     size_t T = align256((size_t)N * CP * H * W * 4);
     size_t S = (size_t)N * P;
     size_t need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
+    if (coherent)   // no plan, no records: the channels-last accumulator (and grad_out_input's copy) is all
+        return need + T + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
     if (!have_plan) need += plan_layout(N, C, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? tl::row2((int)CP) : tl::row1((int)CP)) * 4);   // fat rows
@@ -491,14 +496,47 @@ int tiled_forward(const Problem &pb, const float *input, const float *grid, cons
     return launch_status();
 }
 
+// the coherent-points kernels (cs_coherent.cuh) for this problem
+cs::coh::Launch coh_launch(const Problem &pb) {
+    cs::coh::Launch L;
+    L.d = pb.d;
+    L.f = pb.f;
+    L.kernel = pb.kernel;
+    L.sdt = pb.sdt;
+    L.cq = (int)(cpad(pb.d.C) / 4);
+    L.stream = pb.stream;
+    return L;
+}
+bool coherent_applies(const Problem &pb) {
+    return pb.coherent && g_force_path.load(std::memory_order_relaxed) != 5 && cs::coh::supported(coh_launch(pb));
+}
+// the zeroed channels-last accumulator the coherent kernels add into
+int coherent_accumulator(const Problem &pb, Carve &ws, float *&acc) {
+    const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
+    acc = (float *)ws.take((size_t)T * 4);
+    if (!ws.ok()) return CS_ERR_WORKSPACE;
+    return zero_async(acc, T, pb.stream);
+}
+int coherent_finish(const Problem &pb, const float *acc, float *grad_input) {
+    return unpack_cl(acc, grad_input, pb.d.N, pb.d.C, cpad(pb.d.C), pb.d.vol, pb.stream);
+}
+
 int tiled_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
                    float *grad_input, float *grad_grid, const float *input_cl, const void *plan, void *workspace,
                    size_t workspace_bytes, bool g_leave) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without grad_input nothing is scattered: no plan, no fat rows -- the point kernel gathers and is all there is
-    int rc = prepare(pb, grad_input ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
+    const bool coh = grad_input && coherent_applies(pb);
+    int rc = prepare(pb, grad_input && !coh ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
+    if (coh) {
+        float *acc;
+        rc = coherent_accumulator(pb, ws, acc);
+        if (rc) return rc;
+        rc = cs::coh::backward(coh_launch(pb), gOut, pr.icl, grid, offset, acc, grad_grid);
+        return rc ? rc : coherent_finish(pb, acc, grad_input);
+    }
     if (!grad_input) {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
                                           (const ST *)gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
@@ -524,7 +562,8 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
-    int rc = prepare(pb, gInput ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
+    const bool coh = gInput && coherent_applies(pb);
+    int rc = prepare(pb, gInput && !coh ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
@@ -533,6 +572,13 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         rc = pack_cl(cI, buf, pb.d.N, pb.d.C, pb.d.vol, pb.stream);
         if (rc) return rc;
         cIcl = buf;
+    }
+    if (coh) {
+        float *acc;
+        rc = coherent_accumulator(pb, ws, acc);
+        if (rc) return rc;
+        rc = cs::coh::bb(coh_launch(pb), cIcl, cG, pr.icl, grid, gOut, offset, acc, gGrid, ggOut);
+        return rc ? rc : coherent_finish(pb, acc, gInput);
     }
     // the plan already holds THIS grad_output in sorted order (an earlier stage of the step left it): the point kernel
     // writes the 16-byte D record only and the walkers stream the payload
@@ -564,8 +610,16 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
               const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, bool g_sorted, bool g_leave) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
-    int rc = prepare(pb, CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
+    const bool coh = coherent_applies(pb);
+    int rc = prepare(pb, coh ? CS_STAGE_FORWARD : CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
+    if (coh) {
+        float *acc;
+        rc = coherent_accumulator(pb, ws, acc);
+        if (rc) return rc;
+        rc = cs::coh::bbb(coh_launch(pb), pr.icl, grid, gOut, cG, hG, hO, offset, acc, ggOut);
+        return rc ? rc : coherent_finish(pb, acc, gInput);
+    }
     const bool lean = hO && g_sorted && pr.plan_is_callers && !pr.plan.dense;   // see tiled_bb
     float *fat = (float *)ws.take((size_t)pb.d.S * (lean ? tl::row3((int)cpad(pb.d.C)) : tl::row2((int)cpad(pb.d.C))) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
@@ -1051,10 +1105,33 @@ const char *cs_error_string(int code) {
 }
 
 void cs_debug_force_path(int mode) { g_force_path.store(mode, std::memory_order_relaxed); }
+void cs_debug_coherent_tuning(int samples_per_wave, int waves_per_block) { cs::coh::set_chunk(samples_per_wave, waves_per_block); }
+
+size_t cs_sort_points_bytes(int64_t P) { return cs::sort::workspace_bytes(P); }
+int cs2d_sort_points(const float *points, float *sorted_points, int32_t *perm, int64_t P, int64_t H, int64_t W,
+                     int padding_mode, int align_corners, int multicell, void *workspace, size_t workspace_bytes,
+                     void *stream) {
+    return cs::sort::sort_points(2, points, P, 1, H, W, padding_mode, align_corners, multicell, sorted_points, perm,
+                                 workspace, workspace_bytes, (hipStream_t)stream);
+}
+int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, int64_t P, int64_t D, int64_t H, int64_t W,
+                     int padding_mode, int align_corners, int multicell, void *workspace, size_t workspace_bytes,
+                     void *stream) {
+    return cs::sort::sort_points(3, points, P, D, H, W, padding_mode, align_corners, multicell, sorted_points, perm,
+                                 workspace, workspace_bytes, (hipStream_t)stream);
+}
+int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
+                           int padding_mode, int align_corners, int multicell, void *stream) {
+    return cs::sort::count_tile_changes(dim, points, P, D, H, W, padding_mode, align_corners, multicell, count,
+                                        (hipStream_t)stream);
+}
 
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
+    const bool coherent = (stage & CS_STAGE_POINTS_COHERENT) != 0 && dim == 2 && W <= cs::coh::MAX_SIZE_HOST &&
+                          H <= cs::coh::MAX_SIZE_HOST && g_force_path.load(std::memory_order_relaxed) != 5;
+    stage &= ~CS_STAGE_POINTS_COHERENT;
     if (stage & CS_STAGE_NO_GRAD_INPUT) {
         // grad_input == NULL: nothing is scattered -- no plan, no rows, no accumulator; what is left is the
         // channels-last copy of the table (and of grad_out_input, when the second backward carries one)
@@ -1063,7 +1140,7 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
         const size_t T = cs_pack_bytes(dim, N, C, D, H, W, P);
         return (have_input_cl ? 0 : T) + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
     }
-    if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI);
+    if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI, coherent);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (rows_cl_applies(dim, N, C, P, vol)) {
         if (dense3_applies(N, C, D, H, W, P)) return dense3_workspace(stage, N, C, D, H, W, P, have_input_cl, have_plan, have_cI);
@@ -1115,6 +1192,11 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
     return build_plan(pb, grid, offset, plan);
 }
 
+int cs2d_plan_keeps_sorted_copy(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P) {
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || !tiled_applies(2, N, C, H, W, P)) return 0;
+    return (!plan_layout(N, C, H, W, P).dense && g_force_path.load(std::memory_order_relaxed) != 4) ? 1 : 0;
+}
+
 size_t cs3d_plan_bytes(int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (!rows_cl_applies(3, N, C, P, D * H * W)) return 0;
@@ -1163,6 +1245,18 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         g_leave = layout->leave_sorted_grad_output != 0;                                             \
     }
 
+// the alignment contract of include/cosine_sampler.h: the kernels issue 8-byte accesses on grid-shaped tensors and
+// 16-byte accesses on input-shaped ones, the prepared objects and the workspace
+static bool misaligned(std::initializer_list<const void *> ps, uintptr_t mask) {
+    for (const void *p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & mask) return true;
+    return false;
+}
+#define CS_LIST(...) {__VA_ARGS__}
+#define CS_ALIGNED(grids, tables)                                                        \
+    if (misaligned(CS_LIST grids, pb.dim == 2 ? 7 : 3)) return CS_ERR_INVALID;           \
+    if (misaligned(CS_LIST tables, 15)) return CS_ERR_INVALID;
+
 // zero-element tensors legitimately come with null data pointers
 #define CS_NEED(...)                                                            \
     if (pb.d.S > 0 && pb.d.C > 0 && any_null({__VA_ARGS__})) return CS_ERR_INVALID;
@@ -1173,6 +1267,7 @@ int cs2d_forward(const float *input, const float *grid, const float *offset, flo
                  const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes, void *stream) {
     CS_PROBLEM(2, 1)
     CS_NEED(input, grid, offset, output)
+    CS_ALIGNED((grid), (input, input_cl, plan, workspace))
     pair_streams(pb, {output});
     if (tiled) return tiled_forward(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     if (pb.sdt) return CS_ERR_UNSUPPORTED;   // 16-bit streams: fast paths only (cs_half_streams_supported)
@@ -1186,6 +1281,7 @@ int cs2d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    CS_ALIGNED((grid, grad_grid), (input, grad_input, input_cl, plan, workspace))
     pair_streams(pb, {grad_output});
     if (tiled)
         return tiled_backward(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
@@ -1209,6 +1305,7 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
+    CS_ALIGNED((grid, grad_grid, grad_out_grid), (input, grad_input, grad_out_input, input_cl, plan, workspace))
     // exact + grad_out_input: the grad_out_input -> grad_grid term is only in the direct kernel (run_bb)
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
     pair_streams(pb, {grad_output, grad_grad_out});
@@ -1238,6 +1335,7 @@ int cs2d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid), (input, grad_input, input_cl, plan, workspace))
     pair_streams(pb, {grad_output, grad_grad_out});
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
@@ -1263,6 +1361,7 @@ int cs2d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(2, 1)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid), (input, grad_input, input_cl, plan, workspace))
     pair_streams(pb, {grad_output, grad_grad_out, grad_out_ggout});
     if (tiled)
         return tiled_bbb(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
@@ -1286,6 +1385,7 @@ int cs3d_forward(const float *input, const float *grid, const float *offset, flo
                  void *stream) {
     CS_PROBLEM(3, D)
     CS_NEED(input, grid, offset, output)
+    CS_ALIGNED((grid), (input, input_cl, plan, workspace))
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_forward<3>(pb, input, grid, offset, output, input_cl, workspace, workspace_bytes);
     if (pb.sdt) return CS_ERR_UNSUPPORTED;
@@ -1299,6 +1399,7 @@ int cs3d_backward(const float *grad_output, const float *input, const float *gri
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(grad_output, input, grid, offset, grad_grid)
+    CS_ALIGNED((grid, grad_grid), (input, grad_input, input_cl, plan, workspace))
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_backward<3>(pb, grad_output, input, grid, offset, grad_input, grad_grid, input_cl, plan, workspace,
                                workspace_bytes);
@@ -1321,6 +1422,7 @@ int cs3d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_grid, grad_grad_out)   // grad_input may be NULL: not wanted
+    CS_ALIGNED((grid, grad_grid, grad_out_grid), (input, grad_input, grad_out_input, input_cl, plan, workspace))
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bb<3>(pb, grad_out_input, grad_out_grid, input, grid, grad_output, offset, grad_input, grad_grid,
                          grad_grad_out, input_cl, plan, workspace, workspace_bytes);
@@ -1345,6 +1447,7 @@ int cs3d_backward_backward_backward(const float *input, const float *grid, const
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, grad_out_grid, grad_out_ggrid, offset, grad_input, grad_grad_out)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid), (input, grad_input, input_cl, plan, workspace))
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, nullptr, offset, grad_input,
                           grad_grad_out, input_cl, plan, workspace, workspace_bytes);
@@ -1368,6 +1471,7 @@ int cs3d_bbb_fused(const float *input, const float *grid, const float *grad_outp
     CS_PROBLEM(3, D)
     CS_LAYOUT()
     CS_NEED(input, grid, grad_output, offset, grad_input, grad_grad_out)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid), (input, grad_input, input_cl, plan, workspace))
     if (pb.d.S > 0 && pb.d.C > 0 && rows_cl_applies(3, N, C, P, pb.d.vol))
         return rcl_bbb<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset,
                           grad_input, grad_grad_out, input_cl, plan, workspace, workspace_bytes);
@@ -1394,6 +1498,7 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid, grad_grid3), (input))
     if (pb.sdt) return CS_ERR_UNSUPPORTED;
     return bbb_grid_impl<2>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }
@@ -1409,6 +1514,7 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
+    CS_ALIGNED((grid, grad_out_grid, grad_out_ggrid, grad_grid3), (input))
     if (pb.sdt) return CS_ERR_UNSUPPORTED;
     return bbb_grid_impl<3>(pb, input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, grad_grid3);
 }

@@ -39,7 +39,7 @@ __device__ __forceinline__ Cell3 locate3(const float *g, const Dims &d, const Fl
 }
 
 // (chunks, N) workgroups: histogram of the cells of one chunk of one n   (Plan: ntx = W+1, nty = H+1, ntiles = cells)
-__global__ __launch_bounds__(256) void plan_count3(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_count3(const float *__restrict__ grid, const float *__restrict__ offset,
                                                    Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t hist[];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void plan_count3(const float *__restrict__ gri
 }
 
 // (chunks, N): every sample takes a slot of its cell's bucket -- the final order
-__global__ __launch_bounds__(256) void plan_scatter3(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_scatter3(const float *__restrict__ grid, const float *__restrict__ offset,
                                                      Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t cursor[];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void for_each_tile(const Low3 &q, const Dims &d, cons
 }
 
 // (chunks, N) workgroups: histogram of the tile lists of one chunk of one n
-__global__ __launch_bounds__(256) void plan_count3t(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_count3t(const float *__restrict__ grid, const float *__restrict__ offset,
                                                     Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t hist[];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void plan_count3t(const float *__restrict__ gr
     for (int b = threadIdx.x; b < pl.ntiles; b += 256) dst[b] = hist[b];
 }
 // (chunks, N): every list entry takes a slot of its tile's bucket (any order); key = (p << 9) | code
-__global__ __launch_bounds__(256) void plan_scatter3t(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_scatter3t(const float *__restrict__ grid, const float *__restrict__ offset,
                                                       Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t cursor[];
     const int n = blockIdx.y, chunk = blockIdx.x;

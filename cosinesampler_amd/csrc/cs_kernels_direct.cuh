@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void row_scatter(const float *__restrict__ gri
 // channels-last scratch (N,vol,C) -> caller's (N,C,vol); any C <= 64.  NV nodes per workgroup: every channel
 // plane receives NV*4 contiguous bytes per workgroup (1 KiB at NV = 256; 64 nodes measured 3.6 TB/s).
 __host__ __device__ constexpr int unpack_nv(int C) { return C > 32 ? 128 : 256; }   // tile stays under 64 KiB of LDS
-__global__ __launch_bounds__(256) void unpack_channels_last(const float *__restrict__ in, float *__restrict__ out,
+static __global__ __launch_bounds__(256) void unpack_channels_last(const float *__restrict__ in, float *__restrict__ out,
                                                             int C, int CP, int64_t vol) {   // CP: channels of `in` (padded)
     extern __shared__ float tile[];  // [NV][C+1]
     const int NV = unpack_nv(C);
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void unpack_channels_last(const float *__restr
 __host__ __device__ constexpr int cl4_nv(int CP) { return CP <= 8 ? 1024 : CP <= 16 ? 512 : CP <= 32 ? 256 : 128; }
 __host__ __device__ constexpr size_t cl4_lds(int CP) { return (size_t)CP * (cl4_nv(CP) + 4) * 4; }
 // (N,vol,CP) channels-last -> (N,C,vol) planes
-__global__ __launch_bounds__(256) void unpack_cl4(const float *__restrict__ in, float *__restrict__ out, int C, int CP,
+static __global__ __launch_bounds__(256) void unpack_cl4(const float *__restrict__ in, float *__restrict__ out, int C, int CP,
                                                   int64_t vol) {
     extern __shared__ float tile[];
     const int NV = cl4_nv(CP), LD = NV + 4, CQ = CP >> 2;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void unpack_cl4(const float *__restrict__ in, 
 // 3D tables are packed Z-PAIRED (slots = 2, gridDim.z = 2, shift = H*W): node v gets two rows, its own and the one of the
 // node a z-plane above (zeros past the last plane), so that the 2x2 node rows a sample needs per y -- (x, x+1) x (z, z+1) --
 // are ONE contiguous run of 4*CP floats (cs_points_cl.cuh gather_quad): 3 lines per sample instead of 5.4 at C = 8.
-__global__ __launch_bounds__(256) void pack_cl4(const float *__restrict__ in, float *__restrict__ out, int C, int CP,
+static __global__ __launch_bounds__(256) void pack_cl4(const float *__restrict__ in, float *__restrict__ out, int C, int CP,
                                                 int64_t vol, int64_t shift, int slots) {
     extern __shared__ float tile[];   // [slots][CP][LD]
     const int NV = cl4_nv(CP) / slots, LD = NV + 4, CQ = CP >> 2;

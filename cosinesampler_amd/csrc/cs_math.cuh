@@ -131,6 +131,7 @@ struct Axis {
     float w[2];   // blending weights of the low / high node
     float d1;     // mu k'(t)
     float d2;     // mu^2 k''(t)
+    float t;      // (lo + 1) - i, the blending argument: 1 - t is the position inside the cell (cs_coherent.cuh orders by it)
 };
 
 template <int KERNEL, int ORDER>
@@ -156,6 +157,7 @@ __device__ __forceinline__ Axis make_axis(float g, int size, const Flags &f, int
     a.w[1] = (KERNEL == K_LINEAR) ? (i - fl) : (1.0f - k0);
     a.d1 = mu * k1;
     a.d2 = mu * mu * k2;
+    a.t = t;
     return a;
 }
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ Geo2 locate(float gx, float gy, const Dims &d, const 
 // channels-last repack:  in (N,C,vol) -> out (N,vol,CP), CP = C rounded up to a multiple of 4 (extra channels zero)
 // ------------------------------------------------------------------------------------------------
 // (shift, slots: the z-paired 3D layout, see pack_cl4 in cs_kernels_direct.cuh; 0, 1 otherwise)
-__global__ __launch_bounds__(256) void pack_channels_last(const float *__restrict__ in, float *__restrict__ out,
+static __global__ __launch_bounds__(256) void pack_channels_last(const float *__restrict__ in, float *__restrict__ out,
                                                           int C, int CP, int64_t vol, int64_t shift, int slots) {
     extern __shared__ float tile[];  // [CP][65]
     const int n = blockIdx.y, slot = blockIdx.z;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pack_channels_last(const float *__restric
 // plan kernels
 // ------------------------------------------------------------------------------------------------
 // (chunks, N) workgroups: histogram of tile ids of one chunk of one n
-__global__ __launch_bounds__(256) void plan_count(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_count(const float *__restrict__ grid, const float *__restrict__ offset,
                                                   Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t hist[];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void plan_count(const float *__restrict__ grid
 }
 
 // one thread per (n, tile): exclusive prefix over chunks (in place) and the bucket size
-__global__ __launch_bounds__(256) void plan_scan_chunks(Plan pl, int N, uint32_t *__restrict__ totals) {
+static __global__ __launch_bounds__(256) void plan_scan_chunks(Plan pl, int N, uint32_t *__restrict__ totals) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (int64_t)N * pl.ntiles) return;
     int n = (int)(t / pl.ntiles), b = (int)(t - (int64_t)n * pl.ntiles);
@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *part) 
     }
     return part[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void plan_scan_tiles_local(const uint32_t *__restrict__ totals,
+static __global__ __launch_bounds__(1024) void plan_scan_tiles_local(const uint32_t *__restrict__ totals,
                                                               uint32_t *__restrict__ tile_begin,
                                                               uint32_t *__restrict__ bsum, int64_t count) {
     __shared__ uint32_t part[1024];
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void plan_scan_tiles_local(const uint32_t *__
     if (i < count) tile_begin[i] = inc - v;
     if (threadIdx.x == 1023) bsum[blockIdx.x] = inc;
 }
-__global__ __launch_bounds__(1024) void plan_scan_tiles_sums(uint32_t *__restrict__ bsum, int64_t nblocks) {
+static __global__ __launch_bounds__(1024) void plan_scan_tiles_sums(uint32_t *__restrict__ bsum, int64_t nblocks) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void plan_scan_tiles_sums(uint32_t *__restric
     }
     if (threadIdx.x == 0) bsum[nblocks] = carry;             // grand total
 }
-__global__ __launch_bounds__(1024) void plan_scan_tiles_add(uint32_t *__restrict__ tile_begin,
+static __global__ __launch_bounds__(1024) void plan_scan_tiles_add(uint32_t *__restrict__ tile_begin,
                                                             const uint32_t *__restrict__ bsum, int64_t count,
                                                             int64_t nblocks) {
     const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void plan_scan_tiles_add(uint32_t *__restrict
 }
 
 // (chunks, N): give every sample a slot inside its tile bucket (any order), remember who sits there
-__global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ grid, const float *__restrict__ offset,
+static __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ grid, const float *__restrict__ offset,
                                                     Plan pl, Dims d, Flags f) {
     extern __shared__ uint32_t cursor[];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void plan_scatter(const float *__restrict__ gr
 }
 
 // one workgroup per (n, tile): counting sort of the bucket by local cell id -> final order
-__global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
+static __global__ __launch_bounds__(256) void plan_tile_sort(Plan pl, int64_t P) {
     __shared__ uint32_t cnt[CELLS];
     __shared__ uint32_t scan[CELLS];
     const int64_t t = blockIdx.x;

@@ -173,7 +173,7 @@ def _backward(ctx, grad_out):
         return None, None, None, None, None, None
     grad_out = ops.keep_expanded(grad_out)
     if torch.is_grad_enabled():        # create_graph: the node made here may run a scatter stage on grad_out later
-        ctx.step.expect(_stream(grad_out, ctx.step))
+        ctx.step.expect(grad_out)
     d_input, d_grid = _SamplerBackward.apply(input, grid, grad_out, ctx.offset, ctx.cfg,
                                              _engine_wants(ctx, 0), ctx.step)
     return d_input, d_grid, None, None, None, None
@@ -221,7 +221,7 @@ class _SamplerBackward(Function):
         ctx.step = step
         grad_input, grad_grid = ops.backward(_stream(gOut, step), _f32(input), _f32(grid), offset, cfg.pad,
                                              cfg.align_corners, bool(input_requires_grad), cfg.kernel, cfg.multicell,
-                                             ctx=step)
+                                             ctx=step, go_owner=gOut)
         ctx.save_for_backward(input, grid, gOut)
         return _as(grad_input, input), _as(grad_grid, grid)
 
@@ -231,7 +231,7 @@ class _SamplerBackward(Function):
         if gOutInput is None and gOutGrid is None:
             return None, None, None, None, None, None, None
         if torch.is_grad_enabled():    # create_graph: a third backward through the node made here scatters with gOut again
-            ctx.step.expect(_stream(gOut, ctx.step))
+            ctx.step.expect(gOut)
         gInput, gGrid, ggOut = _SamplerBackwardBackward.apply(input, grid, gOut, _c(gOutInput), _c(gOutGrid),
                                                               ctx.offset, ctx.cfg, ctx.step, _engine_wants(ctx, 0))
         return gInput, gGrid, ggOut, None, None, None, None
@@ -247,10 +247,12 @@ class _SamplerBackwardBackward(Function):
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
+        # ('+mixed' with gOutInput runs on kernels without native 16-bit streams: fp32 there)
+        go = _f32(gOut) if (cfg.kernel & ops.EXACT_MIXED) and gOutInput is not None else _stream(gOut, step)
         gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
-                                                     _stream(gOut, step), offset, cfg.pad, cfg.align_corners,
+                                                     go, offset, cfg.pad, cfg.align_corners,
                                                      gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step,
-                                                     want_grad_input=bool(want_grad_input))
+                                                     want_grad_input=bool(want_grad_input), go_owner=gOut)
         gInput, gGrid, ggOut = _as(gInput, input), _as(gGrid, grid), _as(ggOut, gOut)
         ctx.has_cG = gOutGrid is not None
         if gOutGrid is None:
@@ -276,7 +278,7 @@ class _SamplerBackwardBackward(Function):
         if hO is not None and hO.dtype != gO.dtype:      # mixed types: the streams of one call share one
             gO, hO = _f32(gO), _f32(hO)
         gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), gO, _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
-                                      cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
+                                      cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step, go_owner=gOut)
         # '+mixed' kernels also return the gradient w.r.t. grid here (u_xxx, u_xxy): the reference has none
         # (modules_2d.py:111).  Terms through gOutInput are not propagated, as everywhere at this level.
         gGrid3 = None

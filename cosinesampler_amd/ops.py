@@ -70,6 +70,14 @@ def keep_expanded(t):
     return t.contiguous()
 
 
+def _al(*ts):
+    """The C ABI wants 16-byte aligned tensors (include/cosine_sampler.h, Alignment); a contiguous view can start anywhere
+    in its storage, so such a tensor is copied to fresh memory here (the reference takes any contiguous tensor)."""
+    out = tuple(t.clone(memory_format=torch.contiguous_format) if t is not None and t.is_cuda and t.data_ptr() % 16 else t
+                for t in ts)
+    return out[0] if len(out) == 1 else out
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -128,18 +136,39 @@ def _offset_ok(offset, N, device):
         raise RuntimeError("offset must hold N=%d floats on %s" % (N, device))
 
 
+class _Held(object):
+    """Identity of a tensor's bytes for as long as we HOLD the tensor: the object itself (a strong reference, so that its
+    storage cannot be freed and handed to another tensor with the same address, shape and version 0 -- the caching
+    allocator does exactly that with same-sized temporaries) plus its version counter (in-place updates)."""
+    __slots__ = ("t", "version")
+
+    def __init__(self, t):
+        self.t = t
+        self.version = None if t is None else t._version
+
+    def same(self, t):
+        if t is None or self.t is None:
+            return t is self.t
+        # while self.t is held its storage cannot be re-used, so an equal address means the same memory (an alias)
+        return (t is self.t or (t.data_ptr() == self.t.data_ptr() and t.shape == self.t.shape and t.dtype == self.t.dtype
+                                and t.stride() == self.t.stride())) and t._version == self.version
+
+
 class StepContext(object):
     """Prepared objects that the stages of ONE training step share (include/cosine_sampler.h,
     `input_cl` / `plan`): the channels-last copy of `input` and the point-binning plan of `grid`.
-    Built lazily on first use, keyed on the tensors' storage address, version counter and shape,
-    and dropped with the context.  The autograd Functions create one per forward call, so nothing
+    Built lazily on first use and dropped with the context.  Every derived object is tied to the tensor it was made from
+    by a strong reference and the tensor's version counter (`_Held`): a different tensor object -- even one that the
+    allocator placed at the same address -- or an in-place update invalidates it (the reference reads its own arguments
+    on every call, modules_2d.py:55-62, :89-95).  The autograd Functions create one context per forward call, so nothing
     outlives the graph it belongs to; pass `ctx=None` to let every stage work from scratch."""
 
-    def __init__(self, reuse_grad_output=True):
+    def __init__(self, reuse_grad_output=True, points_order=None):
         self._cl = None
-        self._cl_key = None
+        self._cl_of = None
         self._plan = None
-        self._plan_key = None
+        self._plan_of = None
+        self._plan_cfg = None
         # Whose cell-sorted copy the plan holds (include/cosine_sampler.h, cs_cotangent_layout.sorted_grad_output_valid)
         # and when a stage is asked to leave one (leave_sorted_grad_output: +0.25 ms at config 2, repaid by the next
         # stage that streams it).  reuse_grad_output=True -- a caller driving the stages of one step itself (bench.py,
@@ -149,31 +178,31 @@ class StepContext(object):
         # tensor that `expect()` has announced at least twice.
         self.reuse_grad_output = reuse_grad_output
         self.half_ok = False             # set by the autograd layer: 16-bit streams go to the kernels as they are
-        self._expected = {}
-        self._sorted_go = None
+        self._expected = []              # [_Held, count]
+        self._sorted_go = None           # _Held of the tensor whose sorted copy the plan holds
+        # 'coherent' / 'random' / None (= ops.points_order(), by default measured): do consecutive points share cells?
+        self.points_order = points_order
 
     def expect(self, grad_output):
-        """The autograd layer announces that a node holding this grad_output exists and will hand it to a scatter stage."""
-        k = self._ckey(grad_output)
-        self._expected[k] = self._expected.get(k, 0) + 1
+        """The autograd layer announces that a node holding this grad_output (the CALLER's tensor, before any dtype
+        conversion) exists and will hand it to a scatter stage."""
+        for e in self._expected:
+            if e[0].same(grad_output):
+                e[1] += 1
+                return
+        self._expected.append([_Held(grad_output), 1])
 
-    @staticmethod
-    def _key(t):
-        return (t.data_ptr(), t._version, tuple(t.shape), t.device)
-
-    @staticmethod
-    def _ckey(t):
-        """identity of a cotangent's bytes: address, version counter, shape, strides (+ the testing knob's epoch)"""
-        if t is None:
-            return ("none", _force_epoch)
-        return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), _force_epoch)
+    def _expected_count(self, owner):
+        for e in self._expected:
+            if e[0].same(owner):
+                return e[1]
+        return 0
 
     def input_cl(self, lib, input, dim, shape, P, stream):
-        key = self._key(input)
-        if self._cl_key != key:
+        if self._cl_of is None or not self._cl_of.same(input):
             D = shape[2] if dim == 3 else 1
             nbytes = lib.cs_pack_bytes(dim, shape[0], shape[1], D, shape[-2], shape[-1], P)
-            self._cl, self._cl_key = None, key
+            self._cl, self._cl_of = None, _Held(input)
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
                 _lib.check(lib.cs_pack_input(dim, input.data_ptr(), buf.data_ptr(), shape[0], shape[1], D, shape[-2],
@@ -183,12 +212,11 @@ class StepContext(object):
 
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
         bc = grid.shape[0] == 1 and shape[0] > 1
-        key = self._key(grid) + (offset.data_ptr(),) + tuple(shape[2:]) + (int(padding_mode), bool(align_corners),
-                                                                            bool(multicell), _force_epoch, shape[0])
-        if self._plan_key != key:
+        cfg = (offset.data_ptr(),) + tuple(shape) + (int(padding_mode), bool(align_corners), bool(multicell), _force_epoch)
+        if self._plan_of is None or not self._plan_of.same(grid) or self._plan_cfg != cfg:
             sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
             nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
-            self._plan, self._plan_key = None, key
+            self._plan, self._plan_of, self._plan_cfg = None, _Held(grid), cfg
             self._sorted_go = None
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
@@ -198,7 +226,6 @@ class StepContext(object):
                     "cs%dd_plan_build" % dim)
                 self._plan = buf
         return self._plan
-
 
     def prepare_plan(self, input, grid, offset, padding_mode, align_corners, multicell):
         """Build the point plan of `grid` now, on the current stream (otherwise the first stage that scatters builds it).
@@ -215,9 +242,17 @@ class StepContext(object):
 _force_epoch = 0
 
 
+_force_mode = 0
+_FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST | _lib.POINTS_COHERENT
+
+
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
-          grid=None, offset=None, want_plan=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None):
-    if not isinstance(kernel, int) or (kernel & ~(EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST)) not in (0, 1, 2):
+          grid=None, offset=None, want_grad_input=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
+          go_owner=None):
+    """want_grad_input: the stage produces an input-shaped gradient (it scatters).  go_owner: the caller's tensor that
+    `grad_output` was made from (itself unless the autograd layer converted the dtype): what the sorted copy in the plan
+    is remembered by."""
+    if not isinstance(kernel, int) or (kernel & ~_FLAGS) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
                         "got %r" % (kernel,))
@@ -226,44 +261,147 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
     lib = _lib.load()
     fn = getattr(lib, "cs%dd_%s" % (dim, stage))
     D = shape[2] if dim == 3 else 1
+    owner = grad_output if go_owner is None else go_owner
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
+        # coherent points (CS_POINTS_COHERENT): the scatter stages of the 2D fast path need no plan
+        coherent = bool(want_grad_input and dim == 2 and grid is not None
+                        and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
+        if coherent:
+            kernel |= _lib.POINTS_COHERENT
         cl = plan = None
         if ctx is not None:
             cl = ctx.input_cl(lib, input, dim, shape, P, stream)
-            if want_plan:
+            if want_grad_input and not coherent:
                 plan = ctx.plan(lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream)
         stage_id = _lib.STAGE_ID[stage]
-        if stage in ("backward", "backward_backward") and not want_plan:
+        if stage in ("backward", "backward_backward") and not want_grad_input:
             stage_id |= _lib.STAGE_NO_GRAD_INPUT       # grad_input is not wanted: no plan, no scatter scratch
+        if coherent:
+            stage_id |= _lib.STAGE_POINTS_COHERENT
         need = lib.cs_workspace_bytes(dim, stage_id, shape[0], shape[1], D, shape[-2], shape[-1], P,
                                       int(cl is not None), int(plan is not None), int(have_cI))
         ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
         tail = (_ptr(cl), _ptr(plan), _ptr(ws), need, stream)
+        g_leave = 0
         if stage != "forward":
             CP = shape[1] * P
-            go_key, g_valid, g_leave = None, 0, 0
-            if plan is not None:
-                go_key = ctx._ckey(grad_output)
-                g_valid = int(ctx._sorted_go == go_key)
+            g_valid = 0
+            # the sorted copy of grad_output lives in walker plans of the 2D fast path only, and the '+mixed' second
+            # backward with grad_out_input runs on kernels that neither read nor leave it
+            keeps = (plan is not None and dim == 2 and not ((kernel & EXACT_MIXED) and have_cI)
+                     and bool(lib.cs2d_plan_keeps_sorted_copy(shape[0], shape[1], shape[-2], shape[-1], P)))
+            if keeps:
+                g_valid = int(ctx._sorted_go is not None and ctx._sorted_go.same(owner))
                 if not g_valid:
-                    g_leave = int(ctx.reuse_grad_output or ctx._expected.get(go_key, 0) >= 2)
+                    g_leave = int(ctx.reuse_grad_output or ctx._expected_count(owner) >= 2)
             layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
                                           g_leave)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
-    if stage != "forward" and plan is not None and g_leave:   # the plan now holds this one's sorted copy
-        ctx._sorted_go = go_key
+    if g_leave:   # the plan now holds this one's sorted copy: remember whose, and keep it alive
+        ctx._sorted_go = _Held(owner)
+
+
+# ---- the order of the points ------------------------------------------------------------------------------------
+# Whether consecutive points share cells is a property of the caller's data.  'auto' (default) MEASURES it without ever
+# synchronising: a tiny kernel counts the tile changes of table 0's points (cs_points_tile_changes), the count comes back
+# through a pinned word behind an event, and the decision for a problem signature is the last count that has ARRIVED --
+# so the first call of a signature runs the general path and the decision follows the data one call late.  Both paths
+# give the same results for any order; only the time differs.
+_points_order = "auto"
+_order_state = {}       # signature -> [decision, pending (event, pinned word) or None, device word]
+MIN_COHERENT_SAMPLES = 1 << 16
+
+
+def points_order(mode=None):
+    """Get / set how the op decides whether the points are coherent: 'auto' (measure), 'coherent', 'random'."""
+    global _points_order
+    if mode is not None:
+        if mode not in ("auto", "coherent", "random"):
+            raise ValueError("points order must be 'auto', 'coherent' or 'random', got %r" % (mode,))
+        _points_order = mode
+        _order_state.clear()
+    return _points_order
+
+
+def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream):
+    mode = (ctx.points_order if ctx is not None and ctx.points_order else None) or _points_order
+    if mode != "auto":
+        return mode == "coherent"
+    if shape[0] * P < MIN_COHERENT_SAMPLES:
+        return False
+    sig = (grid.device, tuple(shape), P, int(padding_mode), bool(align_corners), bool(multicell))
+    st = _order_state.get(sig)
+    if st is None:
+        st = _order_state[sig] = [False, None, torch.empty(1, dtype=torch.int32, device=grid.device)]
+    if st[1] is not None and st[1][0].query():       # the previous measurement has arrived
+        changes = int(st[1][1].item())
+        st[0] = changes * 256 <= P
+        st[1] = None
+    if st[1] is None and not torch.cuda.is_current_stream_capturing():
+        _lib.check(lib.cs_points_tile_changes(2, grid.data_ptr(), st[2].data_ptr(), P, 1, shape[-2], shape[-1],
+                                              int(padding_mode), int(bool(align_corners)), int(bool(multicell)), stream),
+                   "cs_points_tile_changes")
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(st[2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st[1] = (ev, host)
+    return st[0]
+
+
+def points_tile_changes(points, size, padding_mode=0, align_corners=True, multicell=True):
+    """How often the 8-cell tile changes between consecutive points ((P, dim) tensor; size = (H, W) or (D, H, W)):
+    about the number of occupied tiles for an ordered set, about P for an unordered one.  Synchronises (returns an int)."""
+    _check(points, "points")
+    dim = points.shape[-1]
+    pts = points.reshape(-1, dim)
+    D, H, W = ([1] + [int(x) for x in size])[-3:]
+    count = torch.empty(1, dtype=torch.int32, device=points.device)
+    with torch.cuda.device(points.device):
+        _lib.check(_lib.load().cs_points_tile_changes(dim, pts.data_ptr(), count.data_ptr(), pts.shape[0], D, H, W,
+                                                      int(padding_mode), int(bool(align_corners)), int(bool(multicell)),
+                                                      torch.cuda.current_stream(points.device).cuda_stream),
+                   "cs_points_tile_changes")
+    return int(count.item())
+
+
+def sort_points(points, size, padding_mode=0, align_corners=True, multicell=True):
+    """Order a point set by the cell it falls into (cs2d_sort_points / cs3d_sort_points): what a PIXEL-style caller does ONCE
+    with its collocation points (reference test/test_2d.py:28-38 draws them once and re-uses them every step) so that the
+    backward stages run on the coherent-points kernels.  points: (..., dim) fp32 CUDA tensor in [-1, 1]; size: (H, W) or
+    (D, H, W) of the tables.  -> (sorted_points like points, perm (P,) int64 with sorted = points.reshape(-1, dim)[perm])."""
+    _check(points, "points")
+    dim = points.shape[-1]
+    if dim not in (2, 3) or len(size) != dim:
+        raise RuntimeError("points must be (..., 2) with size (H, W) or (..., 3) with size (D, H, W)")
+    pts = points.reshape(-1, dim)
+    P = pts.shape[0]
+    out = torch.empty_like(pts)
+    perm = torch.empty(P, dtype=torch.int32, device=points.device)
+    lib = _lib.load()
+    need = lib.cs_sort_points_bytes(P)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+    sizes = [int(x) for x in size]
+    with torch.cuda.device(points.device):
+        stream = torch.cuda.current_stream(points.device).cuda_stream
+        rc = getattr(lib, "cs%dd_sort_points" % dim)(pts.data_ptr(), out.data_ptr(), perm.data_ptr(), P, *sizes,
+                                                     int(padding_mode), int(bool(align_corners)), int(bool(multicell)),
+                                                     ws.data_ptr(), need, stream)
+    _lib.check(rc, "cs%dd_sort_points" % dim)
+    return out.reshape(points.shape), perm.long()
 
 
 def force_path(mode):
     """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 fast paths wherever they exist,
     3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 without the re-use of the sorted grad_output copy
-    between the stages of a step."""
-    global _force_epoch
+    between the stages of a step, 5 = 0 with the coherent-points hint ignored."""
+    global _force_epoch, _force_mode
     _force_epoch += 1
+    _force_mode = int(mode)
     _lib.load().cs_debug_force_path(int(mode))
 
 
@@ -285,6 +423,7 @@ def _stream_kernel(kernel, *streams):
 def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None, out_dtype=None):
     """out_dtype (not in the reference's signature): torch.float16 / torch.bfloat16 to have `output` written in that
     type by the kernel (fast paths only: half_streams_ok); default fp32."""
+    input, grid = _al(input, grid)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     out_dtype = out_dtype or input.dtype
@@ -298,9 +437,12 @@ def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell,
 
 
 def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
-             ctx=None):
+             ctx=None, go_owner=None):
     """-> (grad_input | None, grad_grid); grad_input is None when input_requires_grad is False
     (the reference returns an undefined Tensor, 2d.cpp:73-79)."""
+    if go_owner is None:
+        go_owner = grad_output
+    grad_output, input, grid = _al(grad_output, input, grid)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
@@ -310,16 +452,20 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
     grad_grid = _grid_result(grid, shape[0], bc)
     _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
                             _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
-          ctx, input, grid, offset, want_plan=bool(input_requires_grad), go_ns=go_ns, grad_output=grad_output)
+          ctx, input, grid, offset, want_grad_input=bool(input_requires_grad), go_ns=go_ns, grad_output=grad_output,
+          go_owner=go_owner)
     return grad_input, _grid_reduce(grad_grid, bc)
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True):
+                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True, go_owner=None):
     """-> (grad_input, grad_grid, grad_grad_out).  grad_out_input is only read when
     input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros).
     want_grad_input=False (not in the reference): grad_input is not computed and comes back as None --
     the scatter half of the stage, and the point plan it needs, are skipped."""
+    if go_owner is None:
+        go_owner = grad_output
+    grad_out_input, grad_out_grid, input, grid, grad_output = _al(grad_out_input, grad_out_grid, input, grid, grad_output)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
@@ -338,7 +484,8 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=want_grad_input, have_cI=grad_out_input is not None, go_ns=go_ns, grad_output=grad_output)
+          want_grad_input=bool(want_grad_input), have_cI=grad_out_input is not None, go_ns=go_ns,
+          grad_output=grad_output, go_owner=go_owner)
     return grad_input, _grid_reduce(grad_grid, bc), grad_grad_out
 
 
@@ -346,6 +493,8 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
                                align_corners, input_requires_grad, kernel, multicell, ctx=None):
     """-> (grad_input, grad_grad_out).  `input_requires_grad` is accepted and ignored, as in the
     reference kernel (2d.cu:736)."""
+    go_owner = grad_output
+    input, grid, grad_output, grad_out_grid, grad_out_ggrid = _al(input, grid, grad_output, grad_out_grid, grad_out_ggrid)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
@@ -358,15 +507,19 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns, grad_output=grad_output)
+          want_grad_input=True, go_ns=go_ns, grad_output=grad_output, go_owner=go_owner)
     return grad_input, grad_grad_out
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
-              align_corners, kernel, multicell, ctx=None):
+              align_corners, kernel, multicell, ctx=None, go_owner=None):
     """-> (grad_input, grad_grad_out) of the whole third backward (reference modules_2d.py:98-111):
     grad_input = K4.gInput + K3(gOut := grad_out_ggout, gOutInput := ones).gInput in one pass.
     grad_out_grid / grad_out_ggrid / grad_out_ggout may each be None (= zeros)."""
+    if go_owner is None:
+        go_owner = grad_output
+    input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout = _al(
+        input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
@@ -383,7 +536,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_plan=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output)
+          want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner)
     return grad_input, grad_grad_out
 
 
@@ -392,6 +545,8 @@ def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_g
     """NOT in the reference (whose third backward returns no gradient for grid, modules_2d.py:111): the gradient w.r.t.
     `grid` of <grad_grid2, grad_out_ggrid> + <grad_grad_out, grad_out_ggout>, the second backward's outputs taken
     with every mixed term and grad_out_input absent (include/cosine_sampler.h, cs{2,3}d_bbb_grid).  -> like grid."""
+    input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout = _al(
+        input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout)
     dim, shape, P = _problem(input, grid)
     _offset_ok(offset, shape[0], input.device)
     if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):

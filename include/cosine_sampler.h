@@ -35,6 +35,9 @@
  *     for it).  Problems outside the fast paths (C > 32 in 2D / > 16 in 3D -- smaller counts run zero-padded to 4, 8, 16
  *     or 32 channels --, tiny S) ignore both.
  *   - grid (N,...,dim); with CS_GRID_BROADCAST in `kernel` a single (...,dim) set of points shared by every n.
+ *   - Alignment: `grid`-shaped tensors (grid, grad_grid, grad_out_grid, grad_out_ggrid) on 8 bytes in 2D, 4 in 3D; `input`-shaped
+ *     tensors (input, grad_input, grad_out_input), `input_cl`, `plan` and `workspace` on 16 bytes; streams on their
+ *     element size.  The kernels use 8- and 16-byte accesses on them; a violation returns CS_ERR_INVALID.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
  *   - Thread-safe and re-entrant: the library keeps no mutable global state (the one exception is
@@ -50,7 +53,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 8
+#define CS_ABI_VERSION 9
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -75,12 +78,24 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * still written per n, [N, P, dim] -- the gradient with respect to the shared points is their sum over n, which the
  * caller takes (cosinesampler_amd/ops.py does).  Every path accepts it. */
 #define CS_GRID_BROADCAST 0x4000
+/* OR-ed into `kernel` (a HINT about the caller's data, never about the result): consecutive points of `grid` fall into
+ * the same or neighbouring cells -- the order cs2d_sort_points produces, which a PIXEL-style caller, whose collocation
+ * points are a fixed set re-used every step (test/test_2d.py:28-38), establishes once at set-up.  The 2D backward stages
+ * that produce grad_input then run on kernels that keep everything on chip (cs_coherent.cuh: a wave reduces runs of
+ * equal cell in registers and adds them to a private LDS image of the tile it is walking; the reference's per-sample
+ * atomics, 2d.cu:464-505, :661-712, :850-888): no plan, no records, about a third of the time.  Results are the same for
+ * ANY order of the points (up to the summation order of fp32 adds); a wrong hint only costs time -- an unordered set
+ * empties its window at almost every sample.  cs_points_tile_changes measures an order.  Ignored where it does not apply
+ * (3D, the forward, stages without grad_input, problems outside the 2D fast path). */
+#define CS_POINTS_COHERENT 0x8000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
 /* OR-ed into the stage id: the call will pass grad_input == NULL (first / second backward only) -- nothing is
  * scattered, so neither a plan nor scatter scratch is needed (every derivative a PINN takes with
  * autograd.grad(u, x, create_graph=True) is such a call) */
 #define CS_STAGE_NO_GRAD_INPUT 0x10
+/* OR-ed into the stage id: the call will carry CS_POINTS_COHERENT (no plan; one channels-last accumulator of scratch) */
+#define CS_STAGE_POINTS_COHERENT 0x20
 
 /* How the channel-major cotangents of a backward stage lie in memory.  The reference demands contiguous
  * (N,C,[Do,]Ho,Wo) tensors (CHECK_CONTIGUOUS, 2d.cpp:5), so PIXEL-style callers, which sum the sampled features
@@ -136,6 +151,11 @@ int cs2d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
                     void *stream);
 
+/* 1 if a plan of this problem is the kind that can hold the cell-sorted copy of grad_output (cs_cotangent_layout:
+ * walker plans; crowded tables bin by cell and keep none), else 0: a caller only sets sorted_grad_output_valid after a
+ * stage that was asked to leave the copy on such a plan. */
+int cs2d_plan_keeps_sorted_copy(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P);
+
 /* The same for 3D (C <= 16, run zero-padded to 4, 8 or 16 channels).  Two kinds of plan, chosen by the sizes: small
  * crowded tables (cells = (D+1)(H+1)(W+1) <= 40000 and P >= 8 cells: the reference's test_3d.py shapes) -- samples binned
  * by cell; other tables of up to 12288 tiles of 16x4x4 nodes, P < 2^23 per table (BASELINE configs[3]) -- every sample
@@ -146,10 +166,33 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
                     int padding_mode, int align_corners, int multicell, int flags /* 0 or CS_GRID_BROADCAST */,
                     void *stream);
 
+/* ---- ordering a point set (not in the reference; set-up time, not the per-step path) ------------------------------
+ * cs{2,3}d_sort_points orders P points by the cell of table 0 (offset 0) they fall into -- by 8-cell tiles, then by
+ * cell inside the tile, points that touch no node last; equal cells keep the caller's order (stable, reproducible).
+ *   perm[j]          = index of the point that comes j-th          (int32, P entries)
+ *   sorted_points[j] = points[perm[j]]                              ([P, dim] floats)
+ * A caller orders its collocation points ONCE with this, keeps `perm` if it has per-point data to carry along, and
+ * passes CS_POINTS_COHERENT from then on.  `workspace`: cs_sort_points_bytes(P) bytes of device scratch.
+ * cs_points_tile_changes counts, on the device, how often the tile changes between consecutive points (one uint32 at
+ * `count`, device memory; P for an unordered set, about the number of occupied tiles for an ordered one): the hint pays
+ * when changes * 256 <= P.  Nothing here synchronises; the caller reads `count` when it likes. */
+size_t cs_sort_points_bytes(int64_t P);
+int cs2d_sort_points(const float *points, float *sorted_points, int32_t *perm, int64_t P, int64_t H, int64_t W,
+                     int padding_mode, int align_corners, int multicell, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, int64_t P, int64_t D, int64_t H, int64_t W,
+                     int padding_mode, int align_corners, int multicell, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
+                           int padding_mode, int align_corners, int multicell, void *stream);
+/* Experiments on the coherent kernels: switch parts of them OFF to see what each costs (results are then wrong):
+ * ablation_bits 1 no scatter-reduce, 2 no window flush, 4 no node rows; 0 = the product.  Process-wide. */
+void cs_debug_coherent_tuning(int reserved, int ablation_bits);
+
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
  * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 without the re-use of the sorted grad_output
- * copy between the stages of a step.  Process-wide. */
+ * copy between the stages of a step, 5 = as 0 but CS_POINTS_COHERENT is ignored (A/B of the hint).  Process-wide. */
 void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */

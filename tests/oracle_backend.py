@@ -32,14 +32,14 @@ def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell,
 
 
 def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
-             ctx=None):
+             ctx=None, go_owner=None):
     gi, gg = cs_oracle.backward(_f(grad_output), _f(input), _g(grid, input), offset, padding_mode, align_corners,
                                 input_requires_grad, kernel, multicell)
     return gi, _r(gg, grid, input)
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True):
+                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True, go_owner=None):
     if grad_out_grid is None:
         grad_out_grid = torch.zeros_like(grid)
     gi, gg, ggo = cs_oracle.backward_backward(_f(grad_out_input), _g(grad_out_grid, input), _f(input), _g(grid, input),
@@ -50,7 +50,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
-              align_corners, kernel, multicell, ctx=None):
+              align_corners, kernel, multicell, ctx=None, go_owner=None):
     z = torch.zeros_like(grid)
     return cs_oracle.bbb_fused(_f(input), _g(grid, input), _f(grad_output),
                                _g(z if grad_out_grid is None else grad_out_grid, input),

@@ -125,7 +125,7 @@ def test_unused_table_gradients_are_not_computed(monkeypatch):
     calls = []
     real_backward = ops.backward
 
-    def spy_backward(gO, inp, grid, off, pad, align, input_requires_grad, kern, mc, ctx=None):
+    def spy_backward(gO, inp, grid, off, pad, align, input_requires_grad, kern, mc, ctx=None, go_owner=None):
         calls.append(bool(input_requires_grad))
         return real_backward(gO, inp, grid, off, pad, align, input_requires_grad, kern, mc, ctx=ctx)
 

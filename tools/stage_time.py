@@ -14,6 +14,12 @@ print("N=%d C=%d H=W=%d P=%d" % (N, C, H, P))
 torch.manual_seed(0)
 cells = torch.rand(N, C, H, H, device=dev)
 xy = torch.rand(P, 2, device=dev) * 2 - 1
+if os.environ.get("CS_SORT"):      # points in (16x16-cell tile, cell) order of table 0: what a caller that orders its collocation set hands over
+    TS = int(os.environ["CS_SORT"])
+    cx = ((xy[:, 0] + 1) * 0.5 * (H - 2)).floor().long() + 1
+    cy = ((xy[:, 1] + 1) * 0.5 * (H - 2)).floor().long() + 1
+    key = ((cy // TS) * 64 + cx // TS) * (TS * TS) + (cy % TS) * TS + cx % TS
+    xy = xy[torch.argsort(key)].contiguous()
 grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
 gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
@@ -21,6 +27,10 @@ off = multicell_offset(N, True, dev)
 a = (0, True, 0, True)
 if os.environ.get("CS_FORCE"):
     ops.force_path(int(os.environ["CS_FORCE"]))
+if os.environ.get("CS_ORDER"):      # 'coherent' / 'random': force the hint (default: measured)
+    ops.points_order(os.environ["CS_ORDER"])
+if os.environ.get("CS_ABLATE"):     # coherent kernels with parts switched off (cs_debug_coherent_tuning): results are wrong
+    ops._lib.load().cs_debug_coherent_tuning(0, int(os.environ["CS_ABLATE"]))
 sc = ops.StepContext()
 stages = {
     "forward": lambda: ops.forward(cells, grid, off, *a, ctx=sc),
