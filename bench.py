@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20, help="P per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-helmholtz", action="store_true", help="skip the extra autograd-driven PIXEL step timing")
+    ap.add_argument("--reduce", choices=["per_stage", "once"], default="per_stage",
+                    help="N>1: all-reduce every stage's input-shaped gradient as soon as it is enqueued (3 x 64 MiB, overlapped) "
+                         "or accumulate locally and all-reduce once per step (1 x 64 MiB, SURVEY 8e)")
     ap.add_argument("--rccl-alone", action="store_true",
                     help="with one rank: still create the RCCL process group and run the gradient all-reduces through it")
     args = ap.parse_args()
@@ -248,15 +251,15 @@ def main():
     ev = []
     out_keep = []
 
-    def step(record, reduce=True):
+    def step(record, reduce=True, grid=grid, order=None, ev=ev):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if record else None
         # A fresh StepContext every step: the channels-last copy of `cells` and the point plan of
         # `grid` are rebuilt inside the timed region each step (forward pays the copy, backward the
         # plan), exactly as one CosineSampler2d.apply + its backward chain would.
-        sc = ops.StepContext()
+        sc = ops.StepContext(points_order=order)
         # every input-shaped gradient starts its sum over the ranks the moment its stage has been enqueued (RCCL's own
         # stream, behind the producing kernels) and the step waits once, at the end: only the last one is exposed
-        red = GradReducer(even_alone=args.rccl_alone, enabled=reduce and use_dist)
+        red = GradReducer(even_alone=args.rccl_alone, enabled=reduce and use_dist, schedule=args.reduce)
         if record:
             e[0].record()
         out = ops.forward(cells, grid, off, pad, align, kern, mc, ctx=sc)
@@ -264,7 +267,8 @@ def main():
             e[1].record()
         # the point plan: a function of the grid alone, used by all three backward stages -- built here so that it is
         # timed as what it is instead of inside whichever stage scatters first (it is part of the step either way)
-        sc.prepare_plan(cells, grid, off, pad, align, mc)
+        if order != "coherent":          # (ordered points: the scatter stages need no plan)
+            sc.prepare_plan(cells, grid, off, pad, align, mc)
         if record:
             e[2].record()
         gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc, ctx=sc)
@@ -283,14 +287,14 @@ def main():
         red.finish(out=acc)              # acc = sum over stages (and ranks) of the input-shaped gradients
         return out, gG, bbG, bbO, tO
 
-    def timed(steps, record, reduce=True):
+    def timed(steps, record, reduce=True, **kw):
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(record, reduce)
+            step(record, reduce, **kw)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -311,6 +315,30 @@ def main():
 
     spans = {"forward": 0, "plan": 1, "backward": 2, "backward_backward": 3, "bbb_fused": 4}
     stage_ms = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) for nm, i in spans.items()}
+
+    # The same step on the same points in CELL ORDER -- what a PIXEL-style caller hands over after ordering its (fixed)
+    # collocation set once with ops.sort_points (reference test/test_2d.py:28-38 draws the set once): the scatter stages
+    # then run on the coherent-points kernels (CS_POINTS_COHERENT), no plan.  Reported beside the headline, never instead:
+    # `value` stays the step on the points as drawn.
+    presorted = None
+    if P == (1 << 20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        xy_s, perm = ops.sort_points(xy, (H, H), pad, align, mc)
+        torch.cuda.synchronize()
+        sort_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        xy_s, perm = ops.sort_points(xy, (H, H), pad, align, mc)
+        torch.cuda.synchronize()
+        sort_ms = min(sort_ms, (time.perf_counter() - t0) * 1e3)
+        grid_s = xy_s.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+        ev_s = []
+        for _ in range(args.warmup):
+            step(False, grid=grid_s, order="coherent")
+        el_s = timed(args.steps, True, grid=grid_s, order="coherent", ev=ev_s)
+        st_s = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in ev_s) / len(ev_s) for nm, i in spans.items()}
+        presorted = (el_s / args.steps * 1e3, st_s, sort_ms)
+        del grid_s, xy_s, perm
     ab = algorithmic_bytes(S, C, d, T)
     dom = max(stage_names, key=lambda k: stage_ms[k])
     achieved = ab[dom] / (stage_ms[dom] * 1e-3)
@@ -347,7 +375,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "2D cosine multicell zeros align_corners N=16 C=16 H=W=256 P=%d per GPU: "
                                    "forward + backward + backward_backward + fused third backward%s"
-                                   % (P, " + RCCL all-reduce of the grad_inputs (3 x 64 MiB, overlapped)" if use_dist else ""),
+                                   % (P, (" + RCCL all-reduce of the grad_inputs (%s)" % ("3 x 64 MiB, overlapped" if args.reduce == "per_stage" else "1 x 64 MiB, once per step")) if use_dist else ""),
                        "samples_per_step_per_gpu": S, "sharding": "points (P) across ranks"},
             "roofline": {"bound": "hbm", "kernel": dom, "kernels": STAGE_KERNELS[dom], "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
@@ -356,11 +384,24 @@ def main():
             "stages_ms": stage_ms,
             "stages_frac": {k: ab[k] / (stage_ms[k] * 1e-3) / HBM_PEAK for k in stage_names},
         }
+        if presorted is not None:
+            ms_s, st_s, sort_ms = presorted
+            line["presorted_points"] = {
+                "ms_per_step": ms_s, "Msamples_per_s": world * S / ms_s / 1e3,
+                "roofline_frac": total_bytes / (ms_s * 1e-3) / HBM_PEAK, "sort_ms_once": sort_ms,
+                "stages_ms": st_s, "stages_frac": {k: ab[k] / (st_s[k] * 1e-3) / HBM_PEAK for k in stage_names},
+                "what": "the same step on the same points after ops.sort_points (cs2d_sort_points: by 8-cell tile, then cell; "
+                        "once, at set-up) with the CS_POINTS_COHERENT hint: the three scatter stages run on "
+                        "cs::coh::backward / bb / bbb (run reduction on chip, no plan: its span is ~0); results are the "
+                        "same for any order, only the time differs"}
         if use_dist:
+            line["reduce_schedule"] = args.reduce
             line["ms_per_step_no_reduce"] = no_reduce_ms
             line["allreduce_ms"] = ms_per_step - no_reduce_ms
             line["reduce"] = ("3 RCCL all-reduces of 64 MiB per step (one per input-shaped gradient), each started "
-                              "asynchronously when its stage is enqueued, one wait at the end of the step")
+                              "asynchronously when its stage is enqueued, one wait at the end of the step"
+                              if args.reduce == "per_stage" else
+                              "the three input-shaped gradients are summed locally, then ONE RCCL all-reduce of 64 MiB per step")
         if world == 1 and not args.no_helmholtz:
             del out_keep[:]
             del cells, grid, gOut, hO, cG, hG, acc      # make room: the 3D config holds a 512 MiB table

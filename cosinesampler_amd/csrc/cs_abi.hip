@@ -415,8 +415,8 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     size_t need = 0;
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
-    if (coherent)   // no plan, no records: the channels-last accumulator (and grad_out_input's copy) is all
-        return need + T + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
+    if (coherent && !(stage == CS_STAGE_BACKWARD_BACKWARD && have_cI))   // no plan, no records: the channels-last accumulator is all
+        return need + T;
     if (!have_plan) need += plan_layout(N, C, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? tl::row2((int)CP) : tl::row1((int)CP)) * 4);   // fat rows
@@ -562,7 +562,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
-    const bool coh = gInput && coherent_applies(pb);
+    const bool coh = gInput && !cI && coherent_applies(pb);   // (with grad_out_input: the general path)
     int rc = prepare(pb, gInput && !coh ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     const float *cIcl = nullptr;
@@ -577,7 +577,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         float *acc;
         rc = coherent_accumulator(pb, ws, acc);
         if (rc) return rc;
-        rc = cs::coh::bb(coh_launch(pb), cIcl, cG, pr.icl, grid, gOut, offset, acc, gGrid, ggOut);
+        rc = cs::coh::bb(coh_launch(pb), cG, pr.icl, grid, gOut, offset, acc, gGrid, ggOut);
         return rc ? rc : coherent_finish(pb, acc, gInput);
     }
     // the plan already holds THIS grad_output in sorted order (an earlier stage of the step left it): the point kernel

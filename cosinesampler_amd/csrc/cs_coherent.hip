@@ -11,7 +11,7 @@ namespace cs {
 namespace coh {
 namespace {
 
-std::atomic<int> g_dbg{0};
+std::atomic<int> g_dbg{0}, g_chunk{1024}, g_wpb{2};
 
 int status() {
     hipError_t e = hipGetLastError();
@@ -29,10 +29,12 @@ struct Geometry {
 };
 Geometry geometry(const Launch &L) {
     Geometry g;
-    g.chunk = 64;
+    g.chunk = g_chunk.load(std::memory_order_relaxed);
     g.dbg = g_dbg.load(std::memory_order_relaxed);
-    g.grid = dim3((unsigned)((L.d.P + 255) / 256), (unsigned)L.d.N);
-    g.block = 256;
+    const int64_t waves = (L.d.P + g.chunk - 1) / g.chunk;
+    const int wpb = g_wpb.load(std::memory_order_relaxed);
+    g.grid = dim3((unsigned)((waves + wpb - 1) / wpb), (unsigned)L.d.N);
+    g.block = 64 * wpb;
     return g;
 }
 
@@ -58,8 +60,10 @@ Geometry geometry(const Launch &L) {
 
 }  // namespace
 
-void set_chunk(int, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no node rows
+void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no products
+    if (samples_per_wave >= 64) g_chunk.store((samples_per_wave + 63) / 64 * 64, std::memory_order_relaxed);
     g_dbg.store(ablation_bits & 7, std::memory_order_relaxed);
+    if ((ablation_bits >> 4) >= 1 && (ablation_bits >> 4) <= 4) g_wpb.store(ablation_bits >> 4, std::memory_order_relaxed);   // waves per workgroup
 }
 
 bool supported(const Launch &L) {
@@ -73,25 +77,22 @@ int backward(const Launch &L, const void *gOut, const float *icl, const float *g
     const Geometry g = geometry(L);
     int rc = 0;
     COH_KERNEL(L, COH_CQ(L.cq, {
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, 4) * 4;
+        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, false) * 4;
         rc = allow_lds(backward<KERNEL, CQ, ST>, shm);
-        if (!rc) backward<KERNEL, CQ, ST><<<g.grid, g.block, shm, L.stream>>>((const ST *)gOut, icl, grid, offset, acc, grad_grid, L.d, L.f, g.dbg);
+        if (!rc) backward<KERNEL, CQ, ST><<<g.grid, g.block, shm, L.stream>>>((const ST *)gOut, icl, grid, offset, acc, grad_grid, L.d, L.f, g.chunk, g.dbg);
     }));
     return rc ? rc : status();
 }
 
-int bb(const Launch &L, const float *cIcl, const float *cG, const float *icl, const float *grid, const void *gOut,
-       const float *offset, float *acc, float *gGrid, void *ggOut) {
+int bb(const Launch &L, const float *cG, const float *icl, const float *grid, const void *gOut, const float *offset,
+       float *acc, float *gGrid, void *ggOut) {
     const Geometry g = geometry(L);
     int rc = 0;
-#define COH_BB(HAS_CI)                                                                                                  \
-    COH_KERNEL(L, COH_CQ(L.cq, {                                                                                        \
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, 16) * 4;                      \
-        rc = allow_lds(bb<KERNEL, CQ, HAS_CI, ST>, shm);                                                                \
-        if (!rc) bb<KERNEL, CQ, HAS_CI, ST><<<g.grid, g.block, shm, L.stream>>>(cIcl, cG, icl, grid, (const ST *)gOut, offset, acc, gGrid, (ST *)ggOut, L.d, L.f, g.dbg); \
-    }))
-    if (cIcl) { COH_BB(true); } else { COH_BB(false); }
-#undef COH_BB
+    COH_KERNEL(L, COH_CQ(L.cq, {
+        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, true) * 4;
+        rc = allow_lds(bb<KERNEL, CQ, ST>, shm);
+        if (!rc) bb<KERNEL, CQ, ST><<<g.grid, g.block, shm, L.stream>>>(cG, icl, grid, (const ST *)gOut, offset, acc, gGrid, (ST *)ggOut, L.d, L.f, g.chunk, g.dbg);
+    }));
     return rc ? rc : status();
 }
 
@@ -101,9 +102,9 @@ int bbb(const Launch &L, const float *icl, const float *grid, const void *gOut, 
     int rc = 0;
 #define COH_BBB(TWO)                                                                                                    \
     COH_KERNEL(L, COH_CQ(L.cq, {                                                                                        \
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(TWO, 4) * 4; \
+        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, false) * 4;                                             \
         rc = allow_lds(bbb<KERNEL, CQ, TWO, ST>, shm);                                                                  \
-        if (!rc) bbb<KERNEL, CQ, TWO, ST><<<g.grid, g.block, shm, L.stream>>>(icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, acc, (ST *)ggOut, L.d, L.f, g.dbg); \
+        if (!rc) bbb<KERNEL, CQ, TWO, ST><<<g.grid, g.block, shm, L.stream>>>(icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, acc, (ST *)ggOut, L.d, L.f, g.chunk, g.dbg); \
     }))
     if (hO) { COH_BBB(true); } else { COH_BBB(false); }
 #undef COH_BBB

@@ -25,11 +25,11 @@ struct Launch {
 bool supported(const Launch &L);
 int backward(const Launch &L, const void *gOut, const float *icl, const float *grid, const float *offset, float *acc,
              float *grad_grid);
-int bb(const Launch &L, const float *cIcl, const float *cG, const float *icl, const float *grid, const void *gOut,
-       const float *offset, float *acc, float *gGrid, void *ggOut);
+int bb(const Launch &L, const float *cG, const float *icl, const float *grid, const void *gOut, const float *offset,
+       float *acc, float *gGrid, void *ggOut);   // grad_out_input absent (with it the stage stays on the general path)
 int bbb(const Launch &L, const float *icl, const float *grid, const void *gOut, const float *cG, const float *hG,
         const void *hO, const float *offset, float *acc, void *ggOut);
-void set_chunk(int reserved, int ablation_bits);   // experiments (cs_debug_coherent_tuning)
+void set_chunk(int samples_per_wave, int ablation_bits);   // tuning / experiments (cs_debug_coherent_tuning)
 
 }  // namespace coh
 

@@ -39,27 +39,43 @@ def all_reduce_grad_(grad_input, group=None, async_op=False, even_alone=False):
 
 
 class GradReducer(object):
-    """Overlaps the reduction of the `input`-shaped gradients with the stages that follow.
+    """Sums the `input`-shaped gradients of one training step over the stages and over the ranks.
 
-    A training step produces up to three of them (first, second and third backward), each ready long before the
-    step ends (at config 2: 1.8, 3.0 and 4.7 ms into a 5.3 ms step).  `push(g)` starts `g`'s sum over the ranks right
-    away -- asynchronously, on the communicator's own stream, ordered after the kernels that produced `g` -- and
-    returns at once; `finish(out=)` waits for every collective started so far (the current stream waits, the host
-    does not) and returns their sum.  Only the last gradient's reduction is left exposed: 64 MiB over xGMI.
-    Without a process group (or alone in it) it only sums."""
+    A step produces up to three of them (first, second and third backward), each ready long before the step ends
+    (at config 2: 1.8, 3.0 and 4.7 ms into a 5.3 ms step).  Two schedules:
 
-    def __init__(self, group=None, even_alone=False, enabled=True):
+    * `"per_stage"` (default): `push(g)` starts `g`'s sum over the ranks right away -- asynchronously, on the
+      communicator's own stream, ordered after the kernels that produced `g` -- and returns at once; `finish()` waits
+      for every collective started so far (the current stream waits, the host does not) and adds them up.  Three 64 MiB
+      all-reduces per step, two of them hidden behind the stages that follow; three times the xGMI bytes.
+    * `"once"`: `push` only remembers `g`; `finish()` adds the gradients up locally and runs ONE all-reduce on the sum
+      (what SURVEY 8e words: "one sum all-reduce per training step on the accumulated cells.grad"); a third of the
+      bytes, all of it exposed at the end of the step.
+
+    `push(g)` in the per-stage schedule reduces `g` IN PLACE and asynchronously: the caller must not read or modify a
+    pushed tensor before `finish()` (nothing orders the caller's stream behind the collective until then).
+    `finish(out=)` with nothing pushed zeroes `out` (the sum of nothing) and returns it.
+    Without a process group (or alone in it) both schedules only sum."""
+
+    def __init__(self, group=None, even_alone=False, enabled=True, schedule="per_stage"):
+        if schedule not in ("per_stage", "once"):
+            raise ValueError("schedule must be 'per_stage' or 'once', got %r" % (schedule,))
         self.group = group
         self.even_alone = even_alone
         self.enabled = enabled           # False: only sum locally (bench.py's "without the reduce" timing)
+        self.schedule = schedule
         self._pending = []
 
     def push(self, grad):
-        work = all_reduce_grad_(grad, self.group, async_op=True, even_alone=self.even_alone) if self.enabled else None
+        work = None
+        if self.enabled and self.schedule == "per_stage":
+            work = all_reduce_grad_(grad, self.group, async_op=True, even_alone=self.even_alone)
         self._pending.append((grad, work))
         return grad
 
     def finish(self, out=None):
+        if not self._pending:
+            return out.zero_() if out is not None else None
         total = out
         first = True
         for grad, work in self._pending:
@@ -73,6 +89,8 @@ class GradReducer(object):
                 total.add_(grad)
             first = False
         self._pending = []
+        if self.enabled and self.schedule == "once":
+            all_reduce_grad_(total, self.group, async_op=False, even_alone=self.even_alone)
         return total
 
 

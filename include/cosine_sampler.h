@@ -185,9 +185,10 @@ int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, i
                      void *stream);
 int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
                            int padding_mode, int align_corners, int multicell, void *stream);
-/* Experiments on the coherent kernels: switch parts of them OFF to see what each costs (results are then wrong):
- * ablation_bits 1 no scatter-reduce, 2 no window flush, 4 no node rows; 0 = the product.  Process-wide. */
-void cs_debug_coherent_tuning(int reserved, int ablation_bits);
+/* Tuning / experiments on the coherent kernels: samples_per_wave (a multiple of 64; 0 keeps the value) and ablation_bits,
+ * which switch parts of the kernels OFF to see what each costs (results are then wrong): 1 no scatter-reduce, 2 no window
+ * flush, 4 no products / outputs; 0 = the product.  Process-wide. */
+void cs_debug_coherent_tuning(int samples_per_wave, int ablation_bits);
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables

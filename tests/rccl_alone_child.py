@@ -44,6 +44,13 @@ def main():
         torch.cuda.synchronize()
         want = keep[0] + keep[1] + keep[2]
         assert torch.equal(total, want), float((total - want).abs().max())   # one rank: the sum over ranks is the identity
+        once = GradReducer(even_alone=True, schedule="once")      # the other schedule: one collective on the local sum
+        for k in keep:
+            once.push(k.clone())
+        assert all(w is None for _, w in once._pending)
+        total1 = once.finish(out=torch.empty_like(cells))
+        torch.cuda.synchronize()
+        assert torch.equal(total1, want)
         t = torch.tensor([1.25], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) == 1.25

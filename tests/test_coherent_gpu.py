@@ -392,3 +392,79 @@ def test_misaligned_views_are_accepted():
     rc = lib.cs2d_forward(inp.data_ptr(), grid.clone().data_ptr(), off.data_ptr(), o.data_ptr(), N, C, size[0], size[1], P,
                           0, 1, 0, 1, None, None, None, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == -1, "the C ABI refuses a misaligned input (CS_ERR_INVALID), got %d" % rc
+
+
+def test_full_size_ordered_points_at_the_headline_config():
+    """BASELINE configs[1] sizes (N=16 C=16 256^2, P=2^20) on ordered points: the coherent kernels against the general
+    path on the same inputs (two independent algorithms: run reduction on chip vs sort + records + walkers), and against
+    size-independent properties: blending weights sum to one (sum over the nodes of grad_input = sum over the points of
+    grad_output for points inside the table), and the order of the points cannot matter (the ordered run un-permuted
+    equals the run on the points as drawn)."""
+    N, C, H, P = 16, 16, 256, 1 << 20
+    g = torch.Generator().manual_seed(21)
+    cells = torch.rand(N, C, H, H, generator=g).to(DEV)
+    xy = ((torch.rand(P, 2, generator=g) * 2 - 1) * 0.999).to(DEV)
+    xy_s, perm = ops.sort_points(xy, (H, H))
+    changes = ops.points_tile_changes(xy_s, (H, H))
+    assert changes <= (H // 8 + 1) ** 2 + 2 and changes * 256 <= P
+    off = multicell_offset(N, True, DEV)
+    gOut = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    hO = torch.randn(N, C, 1, P, generator=g).to(DEV)
+    cG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
+    hG = torch.randn(N, 1, P, 2, generator=g).to(DEV)
+
+    def run(pts, go, ho, cg, hg, order):
+        grid = pts.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+        sc = ops.StepContext(points_order=order)
+        r = {}
+        r["gI"], r["gG"] = ops.backward(go, cells, grid, off, 0, True, True, 0, True, ctx=sc)
+        r["bbI"], r["bbG"], r["bbO"] = ops.backward_backward(None, cg, cells, grid, go, off, 0, True, False, 0, True, ctx=sc)
+        r["fI"], r["fO"] = ops.bbb_fused(cells, grid, go, cg, hg, ho, off, 0, True, 0, True, ctx=sc)
+        torch.cuda.synchronize()
+        return r
+
+    pm = perm.to(DEV)
+    go_s, ho_s = gOut[..., pm].contiguous(), hO[..., pm].contiguous()
+    cg_s, hg_s = cG[:, :, pm].contiguous(), hG[:, :, pm].contiguous()
+    coh = run(xy_s, go_s, ho_s, cg_s, hg_s, "coherent")
+    gen = run(xy_s, go_s, ho_s, cg_s, hg_s, "random")
+    for k in coh:
+        assert rel_err(coh[k], gen[k]) <= 1e-5, "coherent vs general path on ordered points: %s %.2e" % (k, rel_err(coh[k], gen[k]))
+    del gen
+    # weights sum to one: every point is inside the table here
+    s_nodes = coh["gI"].double().sum((2, 3))
+    s_pts = go_s.double().sum((2, 3))
+    assert float((s_nodes - s_pts).abs().max()) <= 1e-4 * float(s_pts.abs().max())
+    # the order cannot matter
+    drawn = run(xy, gOut, hO, cG, hG, "random")
+    for k in ("gI", "bbI", "fI"):
+        assert rel_err(coh[k], drawn[k]) <= 1e-5, "ordered vs as drawn: %s" % k
+    inv = torch.empty_like(pm)
+    inv[pm] = torch.arange(P, device=DEV)
+    for k in ("gG", "bbG"):
+        assert rel_err(coh[k][:, :, inv], drawn[k]) <= 1e-5, "ordered vs as drawn: %s" % k
+    for k in ("bbO", "fO"):
+        assert rel_err(coh[k][..., inv], drawn[k]) <= 1e-5, "ordered vs as drawn: %s" % k
+
+
+def test_ordered_points_slice_vs_oracle_at_full_table_size():
+    """... and against the ORACLE on what it can do in seconds: one table of the headline size (256^2, C=16) with 2^16
+    ordered points that all fall into a 24 x 24-cell corner of it (16 per cell, the headline's density)"""
+    N, C, H, P = 2, 16, 256, 1 << 16
+    g = torch.Generator().manual_seed(22)
+    cells = torch.rand(N, C, H, H, generator=g)
+    xy = (torch.rand(P, 2, generator=g) * 2 - 1) * (48.0 / 254.0) - 0.8
+    xy_s, _ = ops.sort_points(xy.to(DEV), (H, H))
+    t = _case(N, C, (H, H), xy_s.cpu(), seed=5)
+    t["inp"] = cells
+    off = offsets(N, True)
+
+    class Oracle(object):
+        def __getattr__(self, name):
+            fn = getattr(cs_oracle, name)
+            return lambda *a, **k: fn(*a)
+    want = _stages(Oracle(), t, off, 0, True, 0, True, "cpu")
+    got = _stages(ops, t, off, 0, True, 0, True, DEV, ctx=ops.StepContext(points_order="coherent"))
+    torch.cuda.synchronize()
+    for k in want:
+        assert_close(got[k], want[k], "ordered points on a 256^2 table vs oracle: %s" % k)

@@ -73,11 +73,19 @@ def _worker(rank, world, port, d, q):
         for a in (0.5, 0.3, 0.2):
             red.push(loc_gc * a)
         red_total = red.finish(out=torch.empty_like(loc_gc))
+        # the other schedule: summed locally, ONE all-reduce per step
+        once = GradReducer(schedule="once")
+        for a in (0.5, 0.3, 0.2):
+            once.push(loc_gc * a)
+        once_total = once.finish(out=torch.empty_like(loc_gc))
+        empty = GradReducer().finish(out=torch.full_like(loc_gc, 7.0))   # nothing pushed: the sum of nothing
         all_reduce_grad_(loc_gc)                                 # the plain form: one collective
         out = gather_points(loc_out)
         ok = (torch.allclose(out, full_out, rtol=0, atol=0)
               and float((loc_gc - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max())
-              and float((red_total - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max()))
+              and float((red_total - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max())
+              and float((once_total - full_gc).abs().max()) <= 1e-5 * float(full_gc.abs().max())
+              and float(empty.abs().max()) == 0.0)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

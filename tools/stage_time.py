@@ -30,7 +30,7 @@ if os.environ.get("CS_FORCE"):
 if os.environ.get("CS_ORDER"):      # 'coherent' / 'random': force the hint (default: measured)
     ops.points_order(os.environ["CS_ORDER"])
 if os.environ.get("CS_ABLATE"):     # coherent kernels with parts switched off (cs_debug_coherent_tuning): results are wrong
-    ops._lib.load().cs_debug_coherent_tuning(0, int(os.environ["CS_ABLATE"]))
+    ops._lib.load().cs_debug_coherent_tuning(int(os.environ.get("CS_CHUNK", "0")), int(os.environ["CS_ABLATE"]))
 sc = ops.StepContext()
 stages = {
     "forward": lambda: ops.forward(cells, grid, off, *a, ctx=sc),
