@@ -109,7 +109,7 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
                       "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
 
 
-def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False):
+def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=False):
     """BASELINE.json configs[2]: the PIXEL-style Helmholtz step driven entirely by torch.autograd
     (reference test/test_2d.py pattern): u = MLP(sum_n sampler(cells, grid)); u_x, u_y; u_xx, u_yy via the
     second backward; loss = mean((u_xx + u_yy + k^2 u)^2); d loss / d cells via the third backward.
@@ -119,8 +119,14 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False):
     cells = torch.rand(N, C, H, H, generator=g).to(dev).requires_grad_(True)
     W1 = (torch.randn(16, C, generator=g) * 0.5).to(dev)
     W2 = (torch.randn(1, 16, generator=g) * 0.5).to(dev)
-    x = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev).requires_grad_(True)
-    y = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    x = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev)
+    y = (torch.rand(P, 1, generator=g) * 2 - 1).to(dev)
+    if sort_points:      # the collocation set is fixed: order it ONCE by cell (ops.sort_points), as a PIXEL caller would at set-up
+        from cosinesampler_amd import ops
+        xy, _ = ops.sort_points(torch.cat([x, y], -1), (H, H))
+        x, y = xy[:, :1].contiguous(), xy[:, 1:].contiguous()
+    x.requires_grad_(True)
+    y.requires_grad_(True)
     ones = torch.ones(P, 1, device=dev)
 
     def one():
@@ -136,8 +142,9 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False):
         (gc,) = torch.autograd.grad(loss, cells)
         return gc
 
-    one()
-    torch.cuda.synchronize()
+    for _ in range(3 if sort_points else 1):     # (the order of the points is measured behind an event: it arrives a call late)
+        one()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
@@ -422,6 +429,12 @@ def main():
                         "copies of the expanded gradients and the MLP), same N,C,H,W,P"}
             ms_b = helmholtz_step(N, C, H, P, dev, broadcast_grid=True)
             line["pixel_helmholtz_autograd"]["ms_per_step_broadcast_grid"] = ms_b
+            line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points"] = helmholtz_step(N, C, H, P, dev, sort_points=True)
+            line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points_broadcast_grid"] = helmholtz_step(
+                N, C, H, P, dev, broadcast_grid=True, sort_points=True)
+            line["pixel_helmholtz_autograd"]["sorted_points"] = (
+                "the same step with the (fixed) collocation points ordered once by cell with ops.sort_points: the op measures "
+                "the order itself (ops.points_order('auto')) and runs the scatter stages on the coherent-points kernels")
             line["pixel_helmholtz_autograd"]["broadcast_grid"] = (
                 "the same step with the points handed over once, a (1,1,P,2) grid (CS_GRID_BROADCAST) instead of "
                 "grid.repeat(N,1,1,1): no 128 MiB repeat, its backward sums are taken by the op")

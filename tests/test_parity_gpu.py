@@ -603,6 +603,90 @@ def test_native_half_streams(dtype, d, C, P):
         ops.force_path(0)
 
 
+@pytest.mark.parametrize("d,C,force,P", [(2, 16, 2, 9000), (2, 6, 2, 9000), (2, 4, 3, 20000), (2, 5, 1, 3000), (3, 8, 2, 9000),
+                                         (3, 4, 1, 3000), (3, 2, 2, 9000)])
+@pytest.mark.parametrize("mc", [True, False])
+def test_broadcast_grid_vs_oracle(d, C, force, P, mc):
+    """SURVEY 8(f)1, against the ORACLE (the self-comparison above shows the two forms agree; this shows they are right):
+    one (1, ..., dim) set of points on every path -- tiled / crowded / direct in 2D, channels-last point kernels with tile
+    and row-atomic scatter / direct in 3D -- against cs_oracle on the points repeated N times (the reference's form,
+    test/test_2d.py:38); everything grid-shaped is the oracle's sum over n."""
+    N = 3
+    sp = ((40, 33) if force != 3 else (16, 16)) if d == 2 else (9, 11, 7)
+    t = _case(d, N, C, sp, P, seed=177 + C + d)
+    off = offsets(N, mc)
+    rep = lambda x: x[:1].repeat((N,) + (1,) * (x.dim() - 1)).contiguous()
+    tr = dict(t)
+    for k in ("grid", "cG", "hG"):
+        tr[k] = rep(t[k])
+    want = {}
+    want["out"] = cs_oracle.forward(tr["inp"], tr["grid"], off, 0, True, 0, mc)
+    want["gI"], want["gG"] = cs_oracle.backward(tr["gOut"], tr["inp"], tr["grid"], off, 0, True, True, 0, mc)
+    want["bbI"], want["bbG"], want["bbO"] = cs_oracle.backward_backward(None, tr["cG"], tr["inp"], tr["grid"], tr["gOut"], off,
+                                                                        0, True, False, 0, mc)
+    want["fI"], want["fO"] = cs_oracle.bbb_fused(tr["inp"], tr["grid"], tr["gOut"], tr["cG"], tr["hG"], tr["hO"], off, 0,
+                                                 True, 0, mc)
+    x = {k: _g(v) for k, v in t.items()}
+    g1, cG1, hG1 = (x[k][:1].contiguous() for k in ("grid", "cG", "hG"))
+    offd = off.to(DEV)
+    ops.force_path(force)
+    try:
+        for shared in (False, True):
+            sc = ops.StepContext(points_order="random") if shared else None
+            got = {}
+            got["out"] = ops.forward(x["inp"], g1, offd, 0, True, 0, mc, ctx=sc)
+            got["gI"], got["gG"] = ops.backward(x["gOut"], x["inp"], g1, offd, 0, True, True, 0, mc, ctx=sc)
+            got["bbI"], got["bbG"], got["bbO"] = ops.backward_backward(None, cG1, x["inp"], g1, x["gOut"], offd, 0, True, False,
+                                                                       0, mc, ctx=sc)
+            got["fI"], got["fO"] = ops.bbb_fused(x["inp"], g1, x["gOut"], cG1, hG1, x["hO"], offd, 0, True, 0, mc, ctx=sc)
+            torch.cuda.synchronize()
+            for k in want:
+                w = want[k].sum(0, keepdim=True) if k in ("gG", "bbG") else want[k]
+                assert_close(got[k], w, "broadcast grid vs oracle d=%d C=%d force=%d mc=%s shared=%s: %s" % (d, C, force, mc, shared, k))
+    finally:
+        ops.force_path(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("d,C,P", [(2, 16, 9000), (2, 6, 9001), (3, 8, 9000), (2, 3, 9000)])
+def test_native_half_streams_vs_oracle(dtype, d, C, P):
+    """SURVEY 8(f)3, against the ORACLE: 16-bit streams on the fast paths vs cs_oracle on the ROUNDED inputs (fp32
+    arithmetic on both sides, so fp32 outputs agree to 1e-5 and 16-bit outputs to the rounding of the type: 2^-11 relative
+    for float16, 2^-8 for bfloat16, taken per tensor against its largest element)."""
+    N = 2
+    sp = (40, 33) if d == 2 else (9, 11, 7)
+    t = _case(d, N, C, sp, P, seed=6150 + C, spread=1.1)
+    for k in ("gOut", "hO"):
+        t[k] = t[k].to(dtype).float()
+    off = offsets(N, True)
+    want = {}
+    want["out"] = cs_oracle.forward(t["inp"], t["grid"], off, 0, True, 0, True)
+    want["gI"], want["gG"] = cs_oracle.backward(t["gOut"], t["inp"], t["grid"], off, 0, True, True, 0, True)
+    want["bbI"], want["bbG"], want["bbO"] = cs_oracle.backward_backward(None, t["cG"], t["inp"], t["grid"], t["gOut"], off,
+                                                                        0, True, False, 0, True)
+    want["fI"], want["fO"] = cs_oracle.bbb_fused(t["inp"], t["grid"], t["gOut"], t["cG"], t["hG"], t["hO"], off, 0, True, 0, True)
+    x = {k: _g(v) for k, v in t.items()}
+    g16, h16 = x["gOut"].to(dtype), x["hO"].to(dtype)
+    offd = off.to(DEV)
+    eps16 = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    ops.force_path(2)
+    try:
+        sc = ops.StepContext(points_order="random")
+        got = {}
+        got["out"] = ops.forward(x["inp"], x["grid"], offd, 0, True, 0, True, ctx=sc, out_dtype=dtype)
+        got["gI"], got["gG"] = ops.backward(g16, x["inp"], x["grid"], offd, 0, True, True, 0, True, ctx=sc)
+        got["bbI"], got["bbG"], got["bbO"] = ops.backward_backward(None, x["cG"], x["inp"], x["grid"], g16, offd, 0, True, False,
+                                                                   0, True, ctx=sc)
+        got["fI"], got["fO"] = ops.bbb_fused(x["inp"], x["grid"], g16, x["cG"], x["hG"], h16, offd, 0, True, 0, True, ctx=sc)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for k in want:
+        is16 = got[k].dtype == dtype
+        assert is16 == (k in ("out", "bbO", "fO"))
+        assert_close(got[k].float(), want[k], "%s streams vs oracle d=%d C=%d: %s" % (dtype, d, C, k), tol=eps16 if is16 else 1e-5)
+
+
 def test_step_context_follows_in_place_updates():
     """The channels-last copy is keyed on the tensor's version counter: an optimizer step on `cells`
     between two uses of one context must not serve stale values."""
