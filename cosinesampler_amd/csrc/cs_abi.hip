@@ -485,12 +485,16 @@ size_t q_lds(int stride, int co_fields) { return (size_t)4 * (64 * stride + tl::
 // point_forward, per wave: one geometry record block + the [C][64] result tile
 size_t point_lds(int C) { return (size_t)4 * (tl::REC_FLOATS + C * tl::OUT_LD) * 4; }
 
+cs::coh::Launch coh_launch(const Problem &pb);
+bool coherent_applies(const Problem &pb);
+
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
                   const float *input_cl, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
+    if (coherent_applies(pb)) return cs::coh::forward(coh_launch(pb), pr.icl, grid, offset, output);
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ, ST><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
                                       pr.icl, grid, offset, (ST *)output, pb.d, pb.f))));
     return launch_status();

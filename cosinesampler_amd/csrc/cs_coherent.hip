@@ -11,7 +11,7 @@ namespace cs {
 namespace coh {
 namespace {
 
-std::atomic<int> g_dbg{0}, g_chunk{1024}, g_wpb{2};
+std::atomic<int> g_dbg{0}, g_chunk{512}, g_wpb{1};
 
 int status() {
     hipError_t e = hipGetLastError();
@@ -58,12 +58,24 @@ Geometry geometry(const Launch &L) {
         default: { using ST = float; COH_KERNEL_((L_).kernel, __VA_ARGS__) } break;                  \
     }
 
+template <int MODE, bool TWO>
+int launch(const Launch &L, const Args &a) {
+    const Geometry g = geometry(L);
+    int rc = 0;
+    COH_KERNEL(L, COH_CQ(L.cq, {
+        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(MODE) * 4;
+        rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, ST>, shm);
+        if (!rc) stage<KERNEL, CQ, MODE, TWO, ST><<<g.grid, g.block, shm, L.stream>>>(a, L.d, L.f, g.chunk, g.dbg);
+    }));
+    return rc ? rc : status();
+}
+
 }  // namespace
 
 void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no products
     if (samples_per_wave >= 64) g_chunk.store((samples_per_wave + 63) / 64 * 64, std::memory_order_relaxed);
-    g_dbg.store(ablation_bits & 7, std::memory_order_relaxed);
-    if ((ablation_bits >> 4) >= 1 && (ablation_bits >> 4) <= 4) g_wpb.store(ablation_bits >> 4, std::memory_order_relaxed);   // waves per workgroup
+    g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 3) << 3, std::memory_order_relaxed);     // + 256: plain output stores, + 512: nontemporal
+    if (((ablation_bits >> 4) & 15) >= 1 && ((ablation_bits >> 4) & 15) <= 4) g_wpb.store((ablation_bits >> 4) & 15, std::memory_order_relaxed);   // waves per workgroup
 }
 
 bool supported(const Launch &L) {
@@ -72,43 +84,54 @@ bool supported(const Launch &L) {
            (L.cq == 1 || L.cq == 2 || L.cq == 4 || L.cq == 8);
 }
 
+int forward(const Launch &L, const float *icl, const float *grid, const float *offset, void *output) {
+    Args a{};
+    a.icl = icl;
+    a.grid = grid;
+    a.offset = offset;
+    a.out_stream = output;
+    return launch<FWD, false>(L, a);
+}
+
 int backward(const Launch &L, const void *gOut, const float *icl, const float *grid, const float *offset, float *acc,
              float *grad_grid) {
-    const Geometry g = geometry(L);
-    int rc = 0;
-    COH_KERNEL(L, COH_CQ(L.cq, {
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, false) * 4;
-        rc = allow_lds(backward<KERNEL, CQ, ST>, shm);
-        if (!rc) backward<KERNEL, CQ, ST><<<g.grid, g.block, shm, L.stream>>>((const ST *)gOut, icl, grid, offset, acc, grad_grid, L.d, L.f, g.chunk, g.dbg);
-    }));
-    return rc ? rc : status();
+    Args a{};
+    a.icl = icl;
+    a.grid = grid;
+    a.offset = offset;
+    a.gOut = gOut;
+    a.acc = acc;
+    a.out_grid = grad_grid;
+    return launch<BWD, false>(L, a);
 }
 
 int bb(const Launch &L, const float *cG, const float *icl, const float *grid, const void *gOut, const float *offset,
        float *acc, float *gGrid, void *ggOut) {
-    const Geometry g = geometry(L);
-    int rc = 0;
-    COH_KERNEL(L, COH_CQ(L.cq, {
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, true) * 4;
-        rc = allow_lds(bb<KERNEL, CQ, ST>, shm);
-        if (!rc) bb<KERNEL, CQ, ST><<<g.grid, g.block, shm, L.stream>>>(cG, icl, grid, (const ST *)gOut, offset, acc, gGrid, (ST *)ggOut, L.d, L.f, g.chunk, g.dbg);
-    }));
-    return rc ? rc : status();
+    Args a{};
+    a.icl = icl;
+    a.grid = grid;
+    a.offset = offset;
+    a.gOut = gOut;
+    a.cG = cG;
+    a.acc = acc;
+    a.out_grid = gGrid;
+    a.out_stream = ggOut;
+    return launch<BB, false>(L, a);
 }
 
 int bbb(const Launch &L, const float *icl, const float *grid, const void *gOut, const float *cG, const float *hG,
         const void *hO, const float *offset, float *acc, void *ggOut) {
-    const Geometry g = geometry(L);
-    int rc = 0;
-#define COH_BBB(TWO)                                                                                                    \
-    COH_KERNEL(L, COH_CQ(L.cq, {                                                                                        \
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(false, false) * 4;                                             \
-        rc = allow_lds(bbb<KERNEL, CQ, TWO, ST>, shm);                                                                  \
-        if (!rc) bbb<KERNEL, CQ, TWO, ST><<<g.grid, g.block, shm, L.stream>>>(icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, acc, (ST *)ggOut, L.d, L.f, g.chunk, g.dbg); \
-    }))
-    if (hO) { COH_BBB(true); } else { COH_BBB(false); }
-#undef COH_BBB
-    return rc ? rc : status();
+    Args a{};
+    a.icl = icl;
+    a.grid = grid;
+    a.offset = offset;
+    a.gOut = gOut;
+    a.hO = hO;
+    a.cG = cG;
+    a.hG = hG;
+    a.acc = acc;
+    a.out_stream = ggOut;
+    return hO ? launch<BBB, true>(L, a) : launch<BBB, false>(L, a);
 }
 
 }  // namespace coh

@@ -22,10 +22,11 @@ struct KeyDims {
     Flags f;
 };
 
-// (tile, cell inside the tile) of the point in table 0 (offset 0), tile-major then cell-major; points that touch
-// no node go last
+// (tile, quad of 2 x 2 (x 2) cells inside the tile, cell inside the quad) of the point in table 0 (offset 0), each
+// row-major: the coherent kernels reduce runs of equal quad and hold one row of a tile's quads on chip
+// (cs_coherent.cuh); points that touch no node go last
 __device__ __forceinline__ uint64_t cell_key(const float *pt, const KeyDims &k, bool tile_only) {
-    uint64_t tile = 0, local = 0;
+    uint64_t tile = 0, quad = 0, sub = 0;
     for (int j = k.dim - 1; j >= 0; --j) {
         float mu;
         const float i = source_index(pt[j], k.size[j], k.f.pad, k.f.align, 0.0f, k.f.multicell, mu);
@@ -33,9 +34,10 @@ __device__ __forceinline__ uint64_t cell_key(const float *pt, const KeyDims &k, 
         const int u = (int)floorf(i) + 1;
         if (u < 0 || u > k.size[j]) return KEY_LAST;
         tile = tile * (uint64_t)k.nt[j] + (uint64_t)(u / TS);
-        local = local * TS + (uint64_t)(u % TS);
+        quad = quad * (TS / 2) + (uint64_t)((u % TS) >> 1);
+        sub = sub * 2 + (uint64_t)(u & 1);
     }
-    return tile_only ? tile : tile * (TS * TS * TS) + local;
+    return tile_only ? tile : tile * (TS * TS * TS) + quad * 8 + sub;
 }
 
 __global__ __launch_bounds__(256) void make_keys(const float *__restrict__ pts, int64_t P, KeyDims k,

@@ -23,6 +23,7 @@ struct Launch {
     hipStream_t stream;
 };
 bool supported(const Launch &L);
+int forward(const Launch &L, const float *icl, const float *grid, const float *offset, void *output);
 int backward(const Launch &L, const void *gOut, const float *icl, const float *grid, const float *offset, float *acc,
              float *grad_grid);
 int bb(const Launch &L, const float *cG, const float *icl, const float *grid, const void *gOut, const float *offset,

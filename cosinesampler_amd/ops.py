@@ -264,8 +264,8 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
     owner = grad_output if go_owner is None else go_owner
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
-        # coherent points (CS_POINTS_COHERENT): the scatter stages of the 2D fast path need no plan
-        coherent = bool(want_grad_input and dim == 2 and grid is not None
+        # coherent points (CS_POINTS_COHERENT): the 2D fast path reads the table through on-chip windows and needs no plan
+        coherent = bool((want_grad_input or stage == "forward") and dim == 2 and grid is not None
                         and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
         if coherent:
             kernel |= _lib.POINTS_COHERENT

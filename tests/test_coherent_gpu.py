@@ -48,12 +48,13 @@ def _order(pts, size, how, pad, align, mc, seed):
 
 
 def _key_reference(pts, size, pad, align, mc):
-    """numpy restatement of the ordering key (cs_sort.hip cell_key): fp32 source index of table 0, 8-cell tiles"""
+    """numpy restatement of the ordering key (cs_sort.hip cell_key): fp32 source index of table 0, 8-cell tiles, quads, cells"""
     pts = pts.numpy().astype(np.float32)
     d = pts.shape[1]
     sizes = list(size)[::-1]            # x (W) first
     tile = np.zeros(len(pts), dtype=np.int64)
-    local = np.zeros(len(pts), dtype=np.int64)
+    quad = np.zeros(len(pts), dtype=np.int64)
+    sub = np.zeros(len(pts), dtype=np.int64)
     last = np.zeros(len(pts), dtype=bool)
     for j in range(d - 1, -1, -1):
         s = sizes[j]
@@ -68,8 +69,9 @@ def _key_reference(pts, size, pad, align, mc):
         last |= (u < 0) | (u > s)
         nt = s // 8 + 1
         tile = tile * nt + np.clip(u, 0, s) // 8
-        local = local * 8 + np.clip(u, 0, s) % 8
-    key = (tile * 512 + local).astype(np.float64)
+        quad = quad * 4 + (np.clip(u, 0, s) % 8) // 2      # 2 x 2 (x 2) cells, row-major inside the tile
+        sub = sub * 2 + np.clip(u, 0, s) % 2                # the cell inside its quad
+    key = (tile * 512 + quad * 8 + sub).astype(np.float64)
     key[last] = np.inf
     return key
 
@@ -118,6 +120,7 @@ def _stages(mod, t, off, pad, align, ke, mc, dev, **kw):
     x = {k: v.to(dev) for k, v in t.items()}
     off = off.to(dev)
     r = {}
+    r["out"] = mod.forward(x["inp"], x["grid"], off, pad, align, ke, mc, **kw)
     r["gI"], r["gG"] = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, True, ke, mc, **kw)
     r["bbI"], r["bbG"], r["bbO"] = mod.backward_backward(x["cI"], x["cG"], x["inp"], x["grid"], x["gOut"], off, pad,
                                                          align, True, ke, mc, **kw)

@@ -10,7 +10,7 @@ for set in \
   "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" ; do
   i=$((i+1))
   rm -rf $R/gpurun_out/cohpmc_$i
-  CS_SORT=8 CS_ORDER=coherent CS_ABLATE=${ABL:-32} timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/cohpmc_$i -- python $R/tools/stage_time.py 2 > $R/gpurun_out/cohpmc_$i.log 2>&1 || echo "pmc group $i failed: $(tail -2 $R/gpurun_out/cohpmc_$i.log)"
+  CS_SORT=8 CS_ORDER=coherent CS_CHUNK=${CK:-512} CS_ABLATE=${ABL:-16} timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/cohpmc_$i -- python $R/tools/stage_time.py 2 > $R/gpurun_out/cohpmc_$i.log 2>&1 || echo "pmc group $i failed: $(tail -2 $R/gpurun_out/cohpmc_$i.log)"
 done
 python - $R/gpurun_out <<'PY' | tee $R/gpurun_out/coh_pmc.txt
 import csv, glob, sys, collections

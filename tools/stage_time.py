@@ -14,12 +14,8 @@ print("N=%d C=%d H=W=%d P=%d" % (N, C, H, P))
 torch.manual_seed(0)
 cells = torch.rand(N, C, H, H, device=dev)
 xy = torch.rand(P, 2, device=dev) * 2 - 1
-if os.environ.get("CS_SORT"):      # points in (16x16-cell tile, cell) order of table 0: what a caller that orders its collocation set hands over
-    TS = int(os.environ["CS_SORT"])
-    cx = ((xy[:, 0] + 1) * 0.5 * (H - 2)).floor().long() + 1
-    cy = ((xy[:, 1] + 1) * 0.5 * (H - 2)).floor().long() + 1
-    key = ((cy // TS) * 64 + cx // TS) * (TS * TS) + (cy % TS) * TS + cx % TS
-    xy = xy[torch.argsort(key)].contiguous()
+if os.environ.get("CS_SORT"):      # the points in the order ops.sort_points gives them: what a caller that orders its collocation set hands over
+    xy, _ = ops.sort_points(xy, (H, H))
 grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
 gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
