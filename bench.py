@@ -109,7 +109,7 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
                       "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
 
 
-def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=False):
+def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=False, grid_leaf=False):
     """BASELINE.json configs[2]: the PIXEL-style Helmholtz step driven entirely by torch.autograd
     (reference test/test_2d.py pattern): u = MLP(sum_n sampler(cells, grid)); u_x, u_y; u_xx, u_yy via the
     second backward; loss = mean((u_xx + u_yy + k^2 u)^2); d loss / d cells via the third backward.
@@ -129,7 +129,24 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=F
     y.requires_grad_(True)
     ones = torch.ones(P, 1, device=dev)
 
+    grid0 = torch.cat([x, y], -1).detach().view(1, 1, P, 2).requires_grad_(True) if grid_leaf else None
+
+    def one_leaf():
+        # the same step with the points kept as ONE (1,1,P,2) leaf that every step hands over again: u_x, u_y are the two
+        # columns of d u / d grid -- the plan of the (unchanged) grid tensor is found in ops.plan_cache instead of rebuilt
+        val = CosineSampler2d.apply(cells, grid0, "zeros", True, "cosine", True)
+        u = torch.tanh(val.sum(0).view(C, -1).t() @ W1.t()) @ W2.t()
+        (gG,) = torch.autograd.grad(u, grid0, ones, create_graph=True)
+        u_x, u_y = gG[0, 0, :, 0:1], gG[0, 0, :, 1:2]
+        (hx,) = torch.autograd.grad(u_x, grid0, ones, create_graph=True)
+        (hy,) = torch.autograd.grad(u_y, grid0, ones, create_graph=True)
+        loss = torch.mean((hx[0, 0, :, 0:1] + hy[0, 0, :, 1:2] + 4.0 * u) ** 2)
+        (gc,) = torch.autograd.grad(loss, cells)
+        return gc
+
     def one():
+        if grid_leaf:
+            return one_leaf()
         grid = torch.cat([x, y], -1).view(1, 1, P, 2)
         if not broadcast_grid:            # the reference pattern (test/test_2d.py:38); broadcast_grid: the same points
             grid = grid.repeat(N, 1, 1, 1)   # handed over once, CS_GRID_BROADCAST (not expressible with the reference op)
@@ -154,7 +171,7 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=F
     return e0.elapsed_time(e1) / steps
 
 
-def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None):
+def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None, warm_plan=False):
     """forward + the three backward stages on synthetic inputs of the given shape (any of BASELINE.json's configs or
     the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step)."""
     from cosinesampler_amd import multicell_offset, ops
@@ -178,15 +195,20 @@ def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=No
         ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, kernel, True, ctx=sc)
         ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, 0, True, kernel, True, ctx=sc)
 
-    for _ in range(3):
-        one()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        one()
-    e1.record()
-    torch.cuda.synchronize()
+    if warm_plan:        # the grid tensor is the same every step: its plan is kept across steps (ops.plan_cache)
+        ops.plan_cache(1)
+    try:
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        ops.plan_cache(0)
     return e0.elapsed_time(e1) / steps, N * P
 
 
@@ -194,6 +216,9 @@ OTHER_SHAPES = [   # (key, what, dim, N, C, size, P, kernel enum)
     ("config_3d", "BASELINE.json configs[3]: 3D smooth-step N=8 C=8 128^3 P=2^19", 3, 8, 8, 128, 1 << 19, 2),
     ("reference_test_shapes", "reference test/test_2d.py shapes: 2D cosine N=96 C=4 16^2 P=100000 (crowded tables)",
      2, 96, 4, 16, 100000, 0),
+    ("channels_32", "2D cosine N=16 C=32 256^2 P=2^20: the widest table the fast path takes whole", 2, 16, 32, 256, 1 << 20, 0),
+    ("channels_64", "2D cosine N=16 C=64 256^2 P=2^20: two channel ranges of 32 through the fast path (ops: channel groups)",
+     2, 16, 64, 256, 1 << 20, 0),
     ("reference_test_shapes_3d", "reference test/test_3d.py shapes: 3D cosine N=50 C=4 16^3 P=100000 (crowded tables)",
      3, 50, 4, 16, 100000, 0),
 ]
@@ -414,8 +439,12 @@ def main():
             del cells, grid, gOut, hO, cG, hG, acc      # make room: the 3D config holds a 512 MiB table
             torch.cuda.empty_cache()
             for key, what, dim_, n_, c_, size_, p_, kern_ in OTHER_SHAPES:   # the same four stages at other shapes
-                ms_o, s_o = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_)
+                ms_o, s_o = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, steps=5 if c_ > 16 else 10)
                 line[key] = {"ms_per_step": ms_o, "Msamples_per_s": s_o / ms_o / 1e3, "what": what}
+                if key == "channels_64":
+                    line[key]["vs_two_32_channel_steps"] = ms_o / (2 * line["channels_32"]["ms_per_step"])
+                if key == "config_3d":     # fixed collocation points: the plan of the (same) grid tensor kept across steps
+                    line[key]["ms_per_step_warm_plan"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, warm_plan=True)[0]
             ms_h, s_h = stage_pipeline_ms(dev, 2, N, C, H, P, 0, stream_dtype=torch.bfloat16)
             line["bf16_streams"] = {"ms_per_step": ms_h, "Msamples_per_s": s_h / ms_h / 1e3,
                                     "what": "the headline step with output / grad_output / grad_grad_out / grad_out_ggout "
@@ -432,6 +461,15 @@ def main():
             line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points"] = helmholtz_step(N, C, H, P, dev, sort_points=True)
             line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points_broadcast_grid"] = helmholtz_step(
                 N, C, H, P, dev, broadcast_grid=True, sort_points=True)
+            from cosinesampler_amd import ops as _ops
+            _ops.plan_cache(1)
+            try:
+                line["pixel_helmholtz_autograd"]["ms_per_step_warm_plan"] = helmholtz_step(N, C, H, P, dev, grid_leaf=True)
+            finally:
+                _ops.plan_cache(0)
+            line["pixel_helmholtz_autograd"]["warm_plan"] = (
+                "the points kept as one (1,1,P,2) leaf tensor handed over every step (u_x, u_y = the columns of d u / d grid) "
+                "with ops.plan_cache(1): the point plan of the unchanged grid tensor is re-used instead of rebuilt")
             line["pixel_helmholtz_autograd"]["sorted_points"] = (
                 "the same step with the (fixed) collocation points ordered once by cell with ops.sort_points: the op measures "
                 "the order itself (ops.points_order('auto')) and runs the scatter stages on the coherent-points kernels")

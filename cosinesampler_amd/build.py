@@ -20,9 +20,11 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libcosine_sampler_hip.so")
 SOURCES = ["cs_abi.hip", "cs_coherent.hip", "cs_sort.hip"]
 ARCH = "gfx950"
-# per-unit flags.  cs_coherent: without the SLP vectoriser -- it packs the per-sample fma chains into v_pk_fma_f32 and
-# keeps a splatted copy of every multiplier alive for them (+64 registers per lane: 92 -> 168 and spills in the forward)
-EXTRA_FLAGS = {"cs_coherent.hip": ["-fno-slp-vectorize"]}
+# Without the SLP vectoriser: it packs the per-sample fma chains into v_pk_fma_f32 and keeps a splatted copy of every
+# multiplier alive for them (cs_coherent forward: 92 -> 168 registers per lane and spills; the other units run 1-3 % faster
+# without it as well, MI355X_MICROARCH.md "packed f32 VALU")
+COMMON_FLAGS = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {}
 
 
 def _deps():
@@ -66,7 +68,7 @@ def _compile(src, hipcc, force, verbose):
         if all(os.path.getmtime(p) <= t for p in _unit_deps(src)):
             return obj
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-function"]
-    cmd += EXTRA_FLAGS.get(src, []) + ["-o", obj, os.path.join(CSRC, src)]
+    cmd += COMMON_FLAGS + EXTRA_FLAGS.get(src, []) + ["-o", obj, os.path.join(CSRC, src)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -531,15 +531,15 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without grad_input nothing is scattered: no plan, no fat rows -- the point kernel gathers and is all there is
-    const bool coh = grad_input && coherent_applies(pb);
+    const bool coh = coherent_applies(pb);
     int rc = prepare(pb, grad_input && !coh ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (coh) {
-        float *acc;
-        rc = coherent_accumulator(pb, ws, acc);
+        float *acc = nullptr;
+        if (grad_input) rc = coherent_accumulator(pb, ws, acc);
         if (rc) return rc;
         rc = cs::coh::backward(coh_launch(pb), gOut, pr.icl, grid, offset, acc, grad_grid);
-        return rc ? rc : coherent_finish(pb, acc, grad_input);
+        return rc || !grad_input ? rc : coherent_finish(pb, acc, grad_input);
     }
     if (!grad_input) {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
@@ -566,7 +566,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
-    const bool coh = gInput && !cI && coherent_applies(pb);   // (with grad_out_input: the general path)
+    const bool coh = !cI && coherent_applies(pb);   // (with grad_out_input: the general path)
     int rc = prepare(pb, gInput && !coh ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     const float *cIcl = nullptr;
@@ -578,11 +578,11 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
         cIcl = buf;
     }
     if (coh) {
-        float *acc;
-        rc = coherent_accumulator(pb, ws, acc);
+        float *acc = nullptr;
+        if (gInput) rc = coherent_accumulator(pb, ws, acc);
         if (rc) return rc;
         rc = cs::coh::bb(coh_launch(pb), cG, pr.icl, grid, gOut, offset, acc, gGrid, ggOut);
-        return rc ? rc : coherent_finish(pb, acc, gInput);
+        return rc || !gInput ? rc : coherent_finish(pb, acc, gInput);
     }
     // the plan already holds THIS grad_output in sorted order (an earlier stage of the step left it): the point kernel
     // writes the 16-byte D record only and the walkers stream the payload

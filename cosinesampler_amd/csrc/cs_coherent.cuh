@@ -329,11 +329,12 @@ struct Args {
 // ~4 batches of an ordered set.
 // `dbg`: experiments only (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window flush, 4 no per-sample products.
 // =====================================================================================================
-template <int KERNEL, int CQ, int MODE, bool TWO, typename ST>
+template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST>
 __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Flags f, int chunk, int dbg) {
     constexpr int C = 4 * CQ;
     using L = Lay<C>;
-    constexpr bool ACC = MODE != FWD;                    // scatters into grad_input
+    constexpr bool IN = MODE != FWD;                     // reads the cotangent stream gOut
+    constexpr bool ACC = IN && SCAT;                     // scatters into grad_input (SCAT false: grad_input not wanted)
     constexpr bool PROD = MODE == BWD || MODE == BB;     // needs the products input[q_a] . gOut
     constexpr bool OUTS = MODE != BWD;                   // produces a channel stream
     constexpr int ORD = MODE == FWD ? 0 : MODE == BWD ? 1 : 2;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     const int64_t p_begin = wv * chunk;
     if (p_begin >= d.P) return;
     const int count = (int)min((int64_t)chunk, d.P - p_begin);       // samples of this wave
-    float *GT = lds + wib * wave_floats<C>(MODE);
+    float *GT = lds + wib * wave_floats<C>(ACC ? MODE : FWD);
     float *KA = GT + C * L::PT;
     float *TW = ACC ? KA + 64 * KP : GT;
     float *AW = TW + L::WIN;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     const float *grid_w = a.grid + (d.gpt(n, p_begin)) * 2;
     const float *cg_w = (MODE >= BB && a.cG) ? a.cG + (d.gpt(n, p_begin)) * 2 : nullptr;
     const float *hg_w = (MODE == BBB && a.hG) ? a.hG + (d.gpt(n, p_begin)) * 2 : nullptr;
-    const ST *go_w = ACC ? (const ST *)a.gOut + (int64_t)n * d.go_ns + p_begin : nullptr;
+    const ST *go_w = IN ? (const ST *)a.gOut + (int64_t)n * d.go_ns + p_begin : nullptr;
     const ST *ho_w = TWO ? (const ST *)a.hO + (int64_t)n * d.ho_ns + p_begin : nullptr;
     ST *os_w = OUTS ? (ST *)a.out_stream + (int64_t)n * d.C * d.P + p_begin : nullptr;
     float *og_w = (MODE == BWD || MODE == BB) ? a.out_grid + ((int64_t)n * d.P + p_begin) * 2 : nullptr;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     // DEPTH register sets of stream loads, each re-issued for the batch DEPTH ahead as soon as its batch is done with it
     struct Pre {
         float2 xy, cg, hg;
-        StreamRegs<ACC ? C : 1, ST> sg;
+        StreamRegs<IN ? C : 1, ST> sg;
         StreamRegs<TWO ? C : 1, ST> sh;
     };
     auto issue = [&](Pre &s, int b) __attribute__((always_inline)) {
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
         s.cg = s.hg = make_float2(0.f, 0.f);
         if (cg_w) s.cg = *at(reinterpret_cast<const float2 *>(cg_w), r * 8u);
         if (hg_w) s.hg = *at(reinterpret_cast<const float2 *>(hg_w), r * 8u);
-        if constexpr (ACC) s.sg.issue(go_w, r * (uint32_t)sizeof(ST), d.P, d.C);
+        if constexpr (IN) s.sg.issue(go_w, r * (uint32_t)sizeof(ST), d.P, d.C);
         if constexpr (TWO) s.sh.issue(ho_w, r * (uint32_t)sizeof(ST), d.P, d.C);
     };
     auto batch = [&](Pre &s, int b0) __attribute__((always_inline)) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
         const bool live = rel < count;
         Geo g;
         make_geo<KERNEL, ORD>(g, s.xy, off, d, f, live);    // the wait of the batch: loads issued DEPTH batches ago
-        if constexpr (ACC) s.sg.arrived(d.C);
+        if constexpr (IN) s.sg.arrived(d.C);
         if constexpr (TWO) s.sh.arrived(d.C);
         const float2 cgb = s.cg, hgb = s.hg;
 

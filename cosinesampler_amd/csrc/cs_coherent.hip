@@ -58,14 +58,14 @@ Geometry geometry(const Launch &L) {
         default: { using ST = float; COH_KERNEL_((L_).kernel, __VA_ARGS__) } break;                  \
     }
 
-template <int MODE, bool TWO>
+template <int MODE, bool TWO, bool SCAT = true>
 int launch(const Launch &L, const Args &a) {
     const Geometry g = geometry(L);
     int rc = 0;
     COH_KERNEL(L, COH_CQ(L.cq, {
-        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(MODE) * 4;
-        rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, ST>, shm);
-        if (!rc) stage<KERNEL, CQ, MODE, TWO, ST><<<g.grid, g.block, shm, L.stream>>>(a, L.d, L.f, g.chunk, g.dbg);
+        const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
+        rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST>, shm);
+        if (!rc) stage<KERNEL, CQ, MODE, TWO, SCAT, ST><<<g.grid, g.block, shm, L.stream>>>(a, L.d, L.f, g.chunk, g.dbg);
     }));
     return rc ? rc : status();
 }
@@ -102,7 +102,7 @@ int backward(const Launch &L, const void *gOut, const float *icl, const float *g
     a.gOut = gOut;
     a.acc = acc;
     a.out_grid = grad_grid;
-    return launch<BWD, false>(L, a);
+    return acc ? launch<BWD, false>(L, a) : launch<BWD, false, false>(L, a);
 }
 
 int bb(const Launch &L, const float *cG, const float *icl, const float *grid, const void *gOut, const float *offset,
@@ -116,7 +116,7 @@ int bb(const Launch &L, const float *cG, const float *icl, const float *grid, co
     a.acc = acc;
     a.out_grid = gGrid;
     a.out_stream = ggOut;
-    return launch<BB, false>(L, a);
+    return acc ? launch<BB, false>(L, a) : launch<BB, false, false>(L, a);
 }
 
 int bbb(const Launch &L, const float *icl, const float *grid, const void *gOut, const float *cG, const float *hG,

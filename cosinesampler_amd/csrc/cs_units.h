@@ -15,7 +15,8 @@ constexpr int64_t MAX_SIZE_HOST = 32766;   // = cs::coh::MAX_SIZE (cs_coherent.c
 
 // one backward stage on the coherent-points path (cs_coherent.cuh).  `cq` = padded channel count / 4 (1, 2, 4 or 8),
 // `kernel` the blending kernel enum, `sdt` the stream element type (0 fp32, 1 half, 2 bfloat16); `acc` the zeroed
-// channels-last accumulator [N][H*W][4*cq] that receives the input-shaped gradient.  Return: 0 or a hipError_t.
+// channels-last accumulator [N][H*W][4*cq] that receives the input-shaped gradient (null in backward / bb: the gradient is
+// not wanted, nothing is scattered).  Return: 0 or a hipError_t.
 struct Launch {
     Dims d;
     Flags f;

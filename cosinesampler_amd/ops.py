@@ -57,6 +57,8 @@ def _check_stream(t, name):
         return t[0].numel() if t.shape[0] else 0
     if t.dim() >= 2 and t.stride(0) == 0 and t[0].is_contiguous():
         return 0
+    if t.dim() >= 2 and t.shape[0] and t[0].is_contiguous() and t.stride(0) >= t[0].numel():
+        return t.stride(0)        # a channel range of a larger stream (channel groups below): the kernels take any n-stride
     raise RuntimeError("%s must be contiguous (or expanded along n only)" % name)
 
 
@@ -154,6 +156,33 @@ class _Held(object):
                                 and t.stride() == self.t.stride())) and t._version == self.version
 
 
+class _PlanEntry(object):
+    """A built point plan: its buffer, the grid it was made from (held, so that an equal address means the same memory),
+    the configuration it was built for, and whose cell-sorted grad_output copy it currently holds."""
+    __slots__ = ("buf", "of", "cfg", "sorted_go")
+
+    def __init__(self, buf, of, cfg):
+        self.buf, self.of, self.cfg, self.sorted_go = buf, of, cfg, None
+
+
+# Plans that outlive a step.  The plan is a function of the grid alone (SURVEY 7: "cached per grid"): a caller that hands the
+# SAME grid tensor to every step -- fixed collocation points, reference test/test_2d.py:28-38 -- need not have it rebuilt
+# (0.35 ms per step at BASELINE configs[1], 0.21 ms at configs[3]).  Off by default: an entry keeps its grid and its plan
+# (150 MiB + the 1 GiB sorted copy at configs[1]) alive; ops.plan_cache(n) keeps the n most recent ones.
+_plan_cache = []
+_plan_cache_size = 0
+
+
+def plan_cache(entries=None):
+    """Get / set how many point plans are kept across steps, keyed on the grid tensor (identity + version counter, the
+    tensor held while its plan is), the offsets and the problem.  0 (default): a plan lives as long as its StepContext."""
+    global _plan_cache_size
+    if entries is not None:
+        _plan_cache_size = max(0, int(entries))
+        del _plan_cache[_plan_cache_size:]
+    return _plan_cache_size
+
+
 class StepContext(object):
     """Prepared objects that the stages of ONE training step share (include/cosine_sampler.h,
     `input_cl` / `plan`): the channels-last copy of `input` and the point-binning plan of `grid`.
@@ -166,9 +195,7 @@ class StepContext(object):
     def __init__(self, reuse_grad_output=True, points_order=None):
         self._cl = None
         self._cl_of = None
-        self._plan = None
-        self._plan_of = None
-        self._plan_cfg = None
+        self._pe = None                  # _PlanEntry
         # Whose cell-sorted copy the plan holds (include/cosine_sampler.h, cs_cotangent_layout.sorted_grad_output_valid)
         # and when a stage is asked to leave one (leave_sorted_grad_output: +0.25 ms at config 2, repaid by the next
         # stage that streams it).  reuse_grad_output=True -- a caller driving the stages of one step itself (bench.py,
@@ -179,9 +206,18 @@ class StepContext(object):
         self.reuse_grad_output = reuse_grad_output
         self.half_ok = False             # set by the autograd layer: 16-bit streams go to the kernels as they are
         self._expected = []              # [_Held, count]
-        self._sorted_go = None           # _Held of the tensor whose sorted copy the plan holds
+        # (_sorted_go: _Held of the tensor whose sorted copy the plan holds -- kept with the plan, which may be shared)
         # 'coherent' / 'random' / None (= ops.points_order(), by default measured): do consecutive points share cells?
         self.points_order = points_order
+
+    @property
+    def _sorted_go(self):
+        return None if self._pe is None else self._pe.sorted_go
+
+    @_sorted_go.setter
+    def _sorted_go(self, held):
+        if self._pe is not None:
+            self._pe.sorted_go = held
 
     def expect(self, grad_output):
         """The autograd layer announces that a node holding this grad_output (the CALLER's tensor, before any dtype
@@ -213,19 +249,30 @@ class StepContext(object):
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
         bc = grid.shape[0] == 1 and shape[0] > 1
         cfg = (offset.data_ptr(),) + tuple(shape) + (int(padding_mode), bool(align_corners), bool(multicell), _force_epoch)
-        if self._plan_of is None or not self._plan_of.same(grid) or self._plan_cfg != cfg:
+        pe = self._pe
+        if pe is None or not pe.of.same(grid) or pe.cfg != cfg:
+            pe = None
+            for i, e in enumerate(_plan_cache):              # a plan of this very grid from an earlier step
+                if e.cfg == cfg and e.of.same(grid):
+                    pe = e
+                    _plan_cache.insert(0, _plan_cache.pop(i))
+                    break
+        if pe is None:
             sizes = shape[:2] + list(shape[2:]) + [P]          # N, C, [D,] H, W, P
             nbytes = getattr(lib, "cs%dd_plan_bytes" % dim)(*sizes)
-            self._plan, self._plan_of, self._plan_cfg = None, _Held(grid), cfg
-            self._sorted_go = None
+            buf = None
             if nbytes:
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
                 _lib.check(getattr(lib, "cs%dd_plan_build" % dim)(
                     grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, *sizes, int(padding_mode),
                     int(bool(align_corners)), int(bool(multicell)), _lib.GRID_BROADCAST if bc else 0, stream),
                     "cs%dd_plan_build" % dim)
-                self._plan = buf
-        return self._plan
+            pe = _PlanEntry(buf, _Held(grid), cfg)
+            if _plan_cache_size and buf is not None:
+                _plan_cache.insert(0, pe)
+                del _plan_cache[_plan_cache_size:]
+        self._pe = pe
+        return pe.buf
 
     def prepare_plan(self, input, grid, offset, padding_mode, align_corners, multicell):
         """Build the point plan of `grid` now, on the current stream (otherwise the first stage that scatters builds it).
@@ -265,7 +312,7 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
         # coherent points (CS_POINTS_COHERENT): the 2D fast path reads the table through on-chip windows and needs no plan
-        coherent = bool((want_grad_input or stage == "forward") and dim == 2 and grid is not None
+        coherent = bool(dim == 2 and grid is not None
                         and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
         if coherent:
             kernel |= _lib.POINTS_COHERENT
@@ -422,11 +469,63 @@ def _stream_kernel(kernel, *streams):
     return kernel | STREAM_DTYPES[dt], dt
 
 
+# ---- channel groups ---------------------------------------------------------------------------------------------
+# The fast paths hold one node's channels in registers / one LDS row: up to 32 channels in 2D, 16 in 3D.  The reference
+# loops over any C (2d.cu:340-354); beyond those counts the direct kernels would take over (51 ms per backward stage at
+# BASELINE configs[1] sizes).  Instead a table with more channels is run as channel ranges of at most that many through the
+# fast paths: the sampler is linear and separable over channels -- `output`, `grad_input`, `grad_grad_out` are per channel
+# (concatenated), `grad_grid` sums over channels (added up).  Input streams are handed over as views (the kernels take their
+# n-stride), the table range is copied once per step (StepContext), per-channel results are concatenated.
+GROUP_CHANNELS = {2: 32, 3: 16}
+
+
+def _channel_groups(input, dim):
+    C, g = int(input.shape[1]), GROUP_CHANNELS[dim]
+    if C <= g or _force_mode == 1:
+        return None
+    return [(a, min(a + g, C)) for a in range(0, C, g)]
+
+
+def _group_ctx(ctx, input, a, b):
+    """-> (the contiguous channel range a:b of `input`, the child context of that range): both live in `ctx`, so that the
+    stages of a step share the range's channels-last copy and plan exactly as they share the whole table's."""
+    if ctx is None:
+        return input[:, a:b].contiguous(), None
+    kids = ctx.__dict__.setdefault("_kids", {})
+    ent = kids.get((a, b))
+    if ent is None or not ent[0].same(input):
+        ent = kids[(a, b)] = (_Held(input), input[:, a:b].contiguous(),
+                              StepContext(reuse_grad_output=ctx.reuse_grad_output, points_order=ctx.points_order))
+    return ent[1], ent[2]
+
+
+def _rng(t, a, b):
+    return None if t is None else t[:, a:b]
+
+
+def _cat(parts):
+    return None if parts[0] is None else torch.cat(parts, 1)
+
+
+def _add(parts):
+    out = parts[0]
+    for x in parts[1:]:
+        out = out + x
+    return out
+
+
 def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None, out_dtype=None):
     """out_dtype (not in the reference's signature): torch.float16 / torch.bfloat16 to have `output` written in that
     type by the kernel (fast paths only: half_streams_ok); default fp32."""
     input, grid = _al(input, grid)
     dim, shape, P = _problem(input, grid)
+    groups = _channel_groups(input, dim)
+    if groups:
+        outs = []
+        for a, b in groups:
+            ig, cg = _group_ctx(ctx, input, a, b)
+            outs.append(forward(ig, grid, offset, padding_mode, align_corners, kernel, multicell, cg, out_dtype))
+        return torch.cat(outs, 1)
     _offset_ok(offset, shape[0], input.device)
     out_dtype = out_dtype or input.dtype
     if out_dtype not in STREAM_DTYPES:
@@ -446,6 +545,17 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
         go_owner = grad_output
     grad_output, input, grid = _al(grad_output, input, grid)
     dim, shape, P = _problem(input, grid)
+    groups = _channel_groups(input, dim)
+    if groups:
+        _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+        gI, gG = [], []
+        for a, b in groups:
+            ig, cg = _group_ctx(ctx, input, a, b)
+            r = backward(_rng(grad_output, a, b), ig, grid, offset, padding_mode, align_corners, input_requires_grad,
+                         kernel, multicell, cg)
+            gI.append(r[0])
+            gG.append(r[1])
+        return _cat(gI), _add(gG)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     kernel, _ = _stream_kernel(kernel, grad_output)
@@ -469,6 +579,21 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         go_owner = grad_output
     grad_out_input, grad_out_grid, input, grid, grad_output = _al(grad_out_input, grad_out_grid, input, grid, grad_output)
     dim, shape, P = _problem(input, grid)
+    groups = _channel_groups(input, dim)
+    if groups:
+        _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+        if input_requires_grad:
+            _same(grad_out_input, input.shape, "grad_out_input", input.device)
+        gI, gG, gO = [], [], []
+        for a, b in groups:
+            ig, cg = _group_ctx(ctx, input, a, b)
+            ci = _rng(grad_out_input, a, b).contiguous() if input_requires_grad else None
+            r = backward_backward(ci, grad_out_grid, ig, grid, _rng(grad_output, a, b), offset, padding_mode,
+                                  align_corners, input_requires_grad, kernel, multicell, cg, want_grad_input)
+            gI.append(r[0])
+            gG.append(r[1])
+            gO.append(r[2])
+        return _cat(gI), _add(gG), torch.cat(gO, 1)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     if input_requires_grad:
@@ -498,6 +623,17 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
     go_owner = grad_output
     input, grid, grad_output, grad_out_grid, grad_out_ggrid = _al(input, grid, grad_output, grad_out_grid, grad_out_ggrid)
     dim, shape, P = _problem(input, grid)
+    groups = _channel_groups(input, dim)
+    if groups:
+        _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+        gI, gO = [], []
+        for a, b in groups:
+            ig, cg = _group_ctx(ctx, input, a, b)
+            r = backward_backward_backward(ig, grid, _rng(grad_output, a, b), grad_out_grid, grad_out_ggrid, offset,
+                                           padding_mode, align_corners, input_requires_grad, kernel, multicell, cg)
+            gI.append(r[0])
+            gO.append(r[1])
+        return torch.cat(gI, 1), torch.cat(gO, 1)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
@@ -523,6 +659,19 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
     input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout = _al(
         input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout)
     dim, shape, P = _problem(input, grid)
+    groups = _channel_groups(input, dim)
+    if groups:
+        _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+        if grad_out_ggout is not None:
+            _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
+        gI, gO = [], []
+        for a, b in groups:
+            ig, cg = _group_ctx(ctx, input, a, b)
+            r = bbb_fused(ig, grid, _rng(grad_output, a, b), grad_out_grid, grad_out_ggrid, _rng(grad_out_ggout, a, b),
+                          offset, padding_mode, align_corners, kernel, multicell, cg)
+            gI.append(r[0])
+            gO.append(r[1])
+        return torch.cat(gI, 1), torch.cat(gO, 1)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
@@ -553,6 +702,11 @@ def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_g
     _offset_ok(offset, shape[0], input.device)
     if not isinstance(kernel, int) or (kernel & ~EXACT_MIXED) not in (0, 1, 2):
         raise TypeError("kernel enum must be 0, 1 or 2, optionally | EXACT_MIXED, got %r" % (kernel,))
+    groups = _channel_groups(input, dim)
+    if groups:
+        return _add([bbb_grid(input[:, a:b].contiguous(), grid, _rng(grad_output, a, b), grad_out_grid, grad_out_ggrid,
+                              _rng(grad_out_ggout, a, b), offset, padding_mode, align_corners, kernel, multicell)
+                     for a, b in groups])
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     if grad_out_ggrid is not None:

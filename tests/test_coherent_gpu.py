@@ -162,8 +162,16 @@ def test_coherent_path_matches_cpu_oracle(C, ke, pad, align, mc, how):
         step = ops.StepContext(points_order="coherent")
         got = _stages(ops, t, off, pad, align, ke, mc, DEV, ctx=step)
         torch.cuda.synchronize()
+        # the same stages when the input-shaped gradient is not wanted: nothing is scattered, the point results stay
+        x = {k: v.to(DEV) for k, v in t.items()}
+        nI, got["gG_only"] = ops.backward(x["gOut"], x["inp"], x["grid"], off.to(DEV), pad, align, False, ke, mc, ctx=step)
+        nI2, got["bbG_only"], got["bbO_only"] = ops.backward_backward(None, x["cG"], x["inp"], x["grid"], x["gOut"], off.to(DEV),
+                                                                      pad, align, False, ke, mc, ctx=step, want_grad_input=False)
+        torch.cuda.synchronize()
+        assert nI is None and nI2 is None
     finally:
         ops.force_path(0)
+    want["gG_only"], want["bbG_only"], want["bbO_only"] = want["gG"], want["bbG0"], want["bbO0"]
     for k in want:
         assert_close(got[k], want[k], "coherent C=%d kernel=%d pad=%d align=%s mc=%s order=%s: %s"
                      % (C, ke, pad, align, mc, how, k))
@@ -548,3 +556,38 @@ def test_full_size_helmholtz_autograd(order):
         tol = 1e-4 if nm in ("u", "u_x") else 5e-4
         assert rel_err(got, want.detach()) <= tol, "full-size Helmholtz (%s points) vs composite: %s %.2e" % (
             order, nm, rel_err(got, want.detach()))
+
+
+def test_plan_cache_reuses_the_plan_of_an_unchanged_grid():
+    """ops.plan_cache: a second step with the SAME grid tensor finds the plan; an in-place change of the grid, another
+    tensor at the same address or a switched-off cache do not.  Results equal the uncached ones bit for bit."""
+    N, C, P, size = 4, 16, 70000, (64, 64)
+    t = _case(N, C, size, _points(P, 2, seed=21), seed=8)
+    off = offsets(N, True).to(DEV)
+    x = {k: v.to(DEV) for k, v in t.items()}
+
+    def step():
+        sc = ops.StepContext(points_order="random")
+        gI, gG = ops.backward(x["gOut"], x["inp"], x["grid"], off, 0, True, True, 0, True, ctx=sc)
+        return sc, gI, gG
+    ops.force_path(2)
+    try:
+        _, gI0, gG0 = step()
+        assert ops.plan_cache(1) == 1
+        sc1, gI1, gG1 = step()
+        sc2, gI2, gG2 = step()
+        assert sc1._pe is not None and sc2._pe is sc1._pe, "the second step re-uses the first one's plan"
+        assert torch.equal(gG1, gG0) and torch.equal(gG2, gG0)
+        assert_close(gI2, gI0, "grad_input from a cached plan")
+        x["grid"].mul_(0.5)                                   # in-place update: another version of the same tensor
+        sc3, gI3, _ = step()
+        assert sc3._pe is not sc1._pe, "an in-place change of the grid invalidates its plan"
+        want = cs_oracle.backward(t["gOut"], t["inp"], t["grid"] * 0.5, offsets(N, True), 0, True, True, 0, True)
+        assert_close(gI3, want[0], "grad_input after the in-place change")
+        ops.plan_cache(0)
+        sc4, _, _ = step()
+        sc5, _, _ = step()
+        assert sc5._pe is not sc4._pe
+    finally:
+        ops.plan_cache(0)
+        ops.force_path(0)

@@ -107,6 +107,11 @@ TILED_CASES += [(5, 0, 0, True, True), (6, 2, 1, False, False), (7, 1, 2, True, 
                 (12, 2, 2, False, True), (24, 0, 0, True, True), (31, 0, 1, True, False)]
 
 
+# more than 32 channels: channel ranges of at most 32 through the same path (ops: channel groups), results concatenated /
+# grad_grid summed -- no cliff to the direct kernels (reference: any C in one loop, 2d.cu:340-354)
+TILED_CASES += [(33, 0, 0, True, True), (48, 2, 1, False, False), (64, 0, 0, True, True), (64, 1, 2, True, False)]
+
+
 @pytest.mark.parametrize("C,ke,pad,align,mc", TILED_CASES)
 @pytest.mark.parametrize("shared", [False, True])
 def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
@@ -183,6 +188,8 @@ TILES3_CASES = [   # C, (W, H, D) as sp = (D, H, W) below, P, kernel, pad, align
     (5, (33, 5, 17), 20000, 1, 0, True, True),      # padded to 8, linear kernel
     (4, (4, 4, 16), 2500, 0, 0, True, True),        # a single tile per (y, z), crowded: many entries with the same code
     (1, (9, 3, 5), 300, 2, 0, False, True),         # tiny
+    (24, (20, 9, 21), 20000, 2, 0, True, True),     # more than 16 channels: ranges of 16 + 8 through the same path
+    (32, (16, 8, 24), 15000, 0, 1, False, True),    # 16 + 16
 ]
 
 
@@ -201,7 +208,7 @@ def test_tiles3_path_matches_cpu_oracle(C, dims, P, ke, pad, align, mc, shared):
     lib = _lib.load()
     ops.force_path(2)
     try:
-        assert lib.cs3d_plan_bytes(N, C, D, H, W, P) > 0 and P < 8 * (D + 1) * (H + 1) * (W + 1)   # a plan, and not the cell one
+        assert lib.cs3d_plan_bytes(N, min(C, 16), D, H, W, P) > 0 and P < 8 * (D + 1) * (H + 1) * (W + 1)   # a plan, and not the cell one
         got = _run_all_stages(_Shared() if shared else ops, t, off, pad, align, ke, mc, DEV)
         torch.cuda.synchronize()
     finally:

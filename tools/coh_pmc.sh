@@ -10,16 +10,16 @@ for set in \
   "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" ; do
   i=$((i+1))
   rm -rf $R/gpurun_out/cohpmc_$i
-  CS_SORT=8 CS_ORDER=coherent CS_CHUNK=${CK:-512} CS_ABLATE=${ABL:-16} timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/cohpmc_$i -- python $R/tools/stage_time.py 2 > $R/gpurun_out/cohpmc_$i.log 2>&1 || echo "pmc group $i failed: $(tail -2 $R/gpurun_out/cohpmc_$i.log)"
+  CS_SORT=${SORTED-8} CS_ORDER=${ORDER:-coherent} CS_CHUNK=${CK:-512} CS_ABLATE=${ABL:-16} timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/cohpmc_$i -- python $R/tools/stage_time.py 2 > $R/gpurun_out/cohpmc_$i.log 2>&1 || echo "pmc group $i failed: $(tail -2 $R/gpurun_out/cohpmc_$i.log)"
 done
-python - $R/gpurun_out <<'PY' | tee $R/gpurun_out/coh_pmc.txt
+python - $R/gpurun_out <<'PY' | tee $R/gpurun_out/${OUT:-coh_pmc}.txt
 import csv, glob, sys, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
 for f in glob.glob(sys.argv[1] + "/cohpmc_*/*/*counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "cs::coh" not in k and "point_forward" not in k: continue
+        if "cs::" not in k or "zero_fill" in k or "plan_" in k: continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if (r["Dispatch_Id"], f) not in seen and r["Counter_Name"] in ("SQ_WAVES", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS"):
             seen.add((r["Dispatch_Id"], f)); calls[(k, f)] += 1
