@@ -120,13 +120,14 @@ struct Windows {
     using L = Lay<C>;
     float *tw, *aw;
     int tqx, aqy;
-    bool dirty, noflush;
+    bool dirty, noflush, noload;
     __device__ __forceinline__ void init(float *t, float *a) {
         tw = t;
         aw = a;
         tqx = aqy = -(1 << 20);
         dirty = false;
         noflush = false;
+        noload = false;
         if (ACC)
             for (int i = threadIdx.x & 63; i < L::WINA; i += 64) aw[i] = 0.0f;
     }
@@ -185,7 +186,7 @@ struct Windows {
         tqx = (int)(key & 0x7FFCu);
         aqy = (int)(key >> 15);
         wave_sync();
-        load_table(tab_n, d);
+        if (!noload) load_table(tab_n, d);
         wave_sync();
     }
 };
@@ -327,7 +328,8 @@ struct Args {
 // ago]  geometry  ->  LDS, vector and matrix work only  ->  the set's next loads go out, then this batch's outputs leave.
 // The windows' global traffic (table rows in, atomics out) happens when the wave moves to another quad row: once per
 // ~4 batches of an ordered set.
-// `dbg`: experiments only (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window flush, 4 no per-sample products.
+// `dbg`: experiments only (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window flush, 4 no per-sample products,
+// 32 no table-window loads, 64 no scatter operands written to LDS.
 // =====================================================================================================
 template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST>
 __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Flags f, int chunk, int dbg) {
@@ -338,7 +340,10 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     constexpr bool PROD = MODE == BWD || MODE == BB;     // needs the products input[q_a] . gOut
     constexpr bool OUTS = MODE != BWD;                   // produces a channel stream
     constexpr int ORD = MODE == FWD ? 0 : MODE == BWD ? 1 : 2;
-    constexpr int DEPTH = MODE == FWD ? 4 : 2;         // batches of stream loads in flight per wave
+    #ifndef CS_COH_DEPTH_BWD
+#define CS_COH_DEPTH_BWD 2
+#endif
+    constexpr int DEPTH = MODE == FWD ? 4 : MODE == BWD ? CS_COH_DEPTH_BWD : 2;         // batches of stream loads in flight per wave
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, n = blockIdx.y;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave in block: a scalar
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     Windows<C, ACC> w;
     w.init(TW, AW);
     w.noflush = (dbg & 2) != 0;
+    w.noload = (dbg & 32) != 0;
     if (ACC) {
         for (int i = lane; i < 64 * KP; i += 64) KA[i] = 0.0f;
     }
@@ -420,8 +426,10 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
         float *blk = KA + lane * KP;
         const int s0 = g.slot0();
         if constexpr (ACC && !TWO) {                        // the scatter operands of the whole batch, once
-            put_coefs(blk, s0, kS);
-            put_rows<C>(GT, s.sg);
+            if (!(dbg & 64)) {
+                put_coefs(blk, s0, kS);
+                put_rows<C>(GT, s.sg);
+            }
         }
         float Y[4] = {0.f, 0.f, 0.f, 0.f};
         float O[OUTS ? C : 1];

@@ -74,7 +74,7 @@ int launch(const Launch &L, const Args &a) {
 
 void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no products
     if (samples_per_wave >= 64) g_chunk.store((samples_per_wave + 63) / 64 * 64, std::memory_order_relaxed);
-    g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 3) << 3, std::memory_order_relaxed);     // + 256: plain output stores, + 512: nontemporal
+    g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 15) << 3, std::memory_order_relaxed);     // + 256 / 512: store policies (unused now), + 1024: no table-window loads, + 2048: no scatter operands to LDS
     if (((ablation_bits >> 4) & 15) >= 1 && ((ablation_bits >> 4) & 15) <= 4) g_wpb.store((ablation_bits >> 4) & 15, std::memory_order_relaxed);   // waves per workgroup
 }
 

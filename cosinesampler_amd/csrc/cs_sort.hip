@@ -55,13 +55,21 @@ __global__ __launch_bounds__(256) void gather_points(const float *__restrict__ p
     for (int j = 0; j < dim; ++j) out[p * dim + j] = pts[s * dim + j];
 }
 __global__ void zero_word(uint32_t *w) { *w = 0; }
+// one counter update per workgroup (with an unordered set every wave has changes: one atomic per wave on the one word
+// took 107 us for 2^20 points; per workgroup it is ~5 us)
 __global__ __launch_bounds__(256) void tile_changes(const float *__restrict__ pts, int64_t P, KeyDims k,
                                                     uint32_t *__restrict__ count) {
+    __shared__ uint32_t wsum[4];
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool change = false;
     if (p < P) change = p == 0 || cell_key(pts + p * k.dim, k, true) != cell_key(pts + (p - 1) * k.dim, k, true);
     const uint64_t m = __ballot(change);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(count, t);
+    }
 }
 
 int key_dims(KeyDims &k, int dim, int64_t D, int64_t H, int64_t W, int pad, int align, int multicell) {

@@ -359,7 +359,7 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
 # so the first call of a signature runs the general path and the decision follows the data one call late.  Both paths
 # give the same results for any order; only the time differs.
 _points_order = "auto"
-_order_state = {}       # signature -> [decision, pending (event, pinned word) or None, device word, calls]
+_order_state = {}       # signature -> [decision, measurement in flight, device word, pinned host word, event]
 MIN_COHERENT_SAMPLES = 1 << 16
 
 
@@ -374,6 +374,9 @@ def points_order(mode=None):
     return _points_order
 
 
+ORDER_SAMPLE_POINTS = 1 << 16      # the order is judged on this many leading points (a 5 us kernel)
+
+
 def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream):
     mode = (ctx.points_order if ctx is not None and ctx.points_order else None) or _points_order
     if mode != "auto":
@@ -383,22 +386,24 @@ def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, mu
     sig = (grid.device, tuple(shape), P, int(padding_mode), bool(align_corners), bool(multicell))
     st = _order_state.get(sig)
     if st is None:
-        st = _order_state[sig] = [False, None, torch.empty(1, dtype=torch.int32, device=grid.device), 0]
-    if st[1] is not None and st[1][0].query():       # the previous measurement has arrived
-        changes = int(st[1][1].item())
-        st[0] = changes * 256 <= P
-        st[1] = None
-    st[3] += 1
-    # measure on the first calls of a signature, then every 8th (the data of a training run keeps its order)
-    if st[1] is None and (st[3] <= 3 or st[3] % 8 == 0) and not torch.cuda.is_current_stream_capturing():
-        _lib.check(lib.cs_points_tile_changes(2, grid.data_ptr(), st[2].data_ptr(), P, 1, shape[-2], shape[-1],
+        # decision, measurement in flight?, device word, pinned host word, event
+        st = _order_state[sig] = [False, False, torch.empty(1, dtype=torch.int32, device=grid.device),
+                                  torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event()]
+    Pm = min(P, ORDER_SAMPLE_POINTS)
+    if st[1] and st[4].query():       # the measurement in flight has arrived
+        st[0] = int(st[3].item()) * 256 <= Pm
+        st[1] = False
+    # One measurement is in flight at any time, every call starts the next as soon as the last has arrived: the decision
+    # trails the data by a call or two.  That matters when a caller goes from an ordered set to an unordered one -- a
+    # stale 'coherent' costs an unordered call 20-40x its time (13-17 ms per stage at BASELINE configs[1], measured) --
+    # so the lag is kept as short as not synchronising allows.
+    if not st[1] and not torch.cuda.is_current_stream_capturing():
+        _lib.check(lib.cs_points_tile_changes(2, grid.data_ptr(), st[2].data_ptr(), Pm, 1, shape[-2], shape[-1],
                                               int(padding_mode), int(bool(align_corners)), int(bool(multicell)), stream),
                    "cs_points_tile_changes")
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        host.copy_(st[2], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st[1] = (ev, host)
+        st[3].copy_(st[2], non_blocking=True)
+        st[4].record()
+        st[1] = True
     return st[0]
 
 

@@ -5,8 +5,17 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function $3 \
-      -o $R/cosinesampler_amd/lib/alt_$2.so $R/cosinesampler_amd/csrc/cs_abi.hip
+  # UNIT (default cs_abi) is recompiled with the extra flags and linked with the other units' objects of the default build
+  U=${UNIT:-cs_abi}
+  python -m cosinesampler_amd.build > /dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS--fno-slp-vectorize} $3 \
+      -o $R/cosinesampler_amd/lib/obj/alt_$2_$U.o $R/cosinesampler_amd/csrc/$U.hip
+  OBJS=""
+  for u in cs_abi cs_coherent cs_sort; do
+    if [ $u = $U ]; then OBJS="$OBJS $R/cosinesampler_amd/lib/obj/alt_$2_$U.o"; else OBJS="$OBJS $R/cosinesampler_amd/lib/obj/$u.o"; fi
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$R/cosinesampler_amd/csrc/exports.map \
+      -o $R/cosinesampler_amd/lib/alt_$2.so $OBJS
   echo built alt_$2.so
 elif [ "$1" = run ]; then
   shift

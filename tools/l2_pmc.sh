@@ -17,10 +17,16 @@ for set in \
   "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
   "TCP_TCR_RDRET_STALL_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-  "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum" \
-  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM" \
-  "GRBM_GUI_ACTIVE GRBM_COUNT SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" ; do
+  "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
+  "TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum" \
+  "TD_TC_STALL_sum GRBM_GUI_ACTIVE GRBM_COUNT" \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+  "SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM" \
+  "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/l2pmc_$i -- $BIN once > $R/gpurun_out/l2pmc_$i.log 2>&1 || echo "pmc group $i ($set) failed"
+  if [ $i -lt ${FIRST:-1} ]; then continue; fi
+  # at most 4 counters of one block per pass (TA / TD / SQ groups of 5-8 abort rocprofv3 at start-up with error 38:
+  # "Request exceeds the capabilities of the hardware", gpurun_out/l2pmc_12.log of round 2); every pass under a timeout
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/l2pmc_$i -- $BIN once > $R/gpurun_out/l2pmc_$i.log 2>&1 || echo "pmc group $i ($set) failed"
   echo "group $i done"
 done

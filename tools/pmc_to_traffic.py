@@ -17,16 +17,21 @@ import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % tag, "*", "*counter_collection.csv"))):
-    for r in csv.DictReader(open(f)):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "cs::" in k or "zero_fill" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {}
 for k, v in agg.items():
-    c = {name: vals[-1] for name, vals in v.items()}          # the last launch of the run (steady state)
+    # bench.py --steps 1 --warmup 1: a kernel's launch 0 is the warm-up step, launch 1 the timed step of the FIRST section
+    # that uses it -- the headline step (drawn points, then ordered points), then the other shapes, then the autograd-driven
+    # Helmholtz steps, whose launches of the same kernels see other cotangent layouts (and, after a change of the points'
+    # order, one or two calls on the wrong path).  So: launch 1, not the last one.
+    c = {name: vals[1] if len(vals) > 1 else vals[-1] for name, vals in v.items()}
     d = {"launches_seen": max(len(x) for x in v.values()), "counters": c}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         d["raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
@@ -59,6 +64,12 @@ stages = {
     "backward": ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
     "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
+    # the headline step on ORDERED points (bench.py presorted_points): coherent kernels, no plan; each scatter stage also
+    # clears a channels-last accumulator (zero_fill, T bytes written) and unpacks it (cs::unpack_cl4)
+    "ordered_forward": ["cs::pack_cl4", "cs::coh::stage<0, 4, 0, false, true, float>"],
+    "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float>", "cs::unpack_cl4"],
+    "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float>", "cs::unpack_cl4"],
+    "ordered_bbb_fused": ["cs::coh::stage<0, 4, 3, true, true, float>", "cs::unpack_cl4"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
     "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2, float>"],
     "3d_plan": ["cs::tiles3::plan_count3t", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiles3::plan_scatter3t"],
@@ -73,7 +84,8 @@ out = {"source": "rocprofv3 --pmc, one pass per counter group, python bench.py -
        "csrc_digest": bench.csrc_digest(),
        "bytes_per_launch": {}, "raw": {}, "by_request_size": {}}
 for st, ks in stages.items():
-    extra = T if st in ("backward", "backward_backward", "bbb_fused") else 0
+    extra = T if st in ("backward", "backward_backward", "bbb_fused", "ordered_backward", "ordered_backward_backward",
+                        "ordered_bbb_fused") else 0
     out["bytes_per_launch"][st] = total(ks, "corrected") + extra
     out["raw"][st] = total(ks, "raw") + extra
     out["by_request_size"][st] = total(ks, "by_size") + extra

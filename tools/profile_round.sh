@@ -1,12 +1,12 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): kernel trace + stats and the PMC passes of the default bench (2D headline, the other
 # shapes and the autograd-driven Helmholtz step run in the same process), summaries under gpurun_out/.
-#   bash tools/profile_round.sh round2      then, in the repo:  python tools/pmc_to_traffic.py round2
+#   bash tools/profile_round.sh round3      then, in the repo:  python tools/pmc_to_traffic.py round3
 # One rocprofv3 run per counter group (the TCC block has 4 slots; FETCH_SIZE costs 3, WRITE_SIZE 2), --pmc never combined
 # with tracing.  Each run is bounded: a profiler that hangs must not take the box with it.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-round2}
+TAG=${1:-round3}
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1 || echo "kernel-trace failed"
 echo "kernel trace done"
 i=0
