@@ -384,6 +384,16 @@ int pack_cl(const float *in, float *out, int64_t N, int64_t C, int64_t vol, hipS
     if ((vol & 3) == 0 && (plane & 3) == 0 && CP <= 64 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {   // 16-byte accesses on both sides
         const int nv = cs::cl4_nv((int)CP) / slots;                 // both slots of a node leave from one workgroup
         const size_t shm = (size_t)slots * CP * (nv + 4) * 4;
+        if (slots == 2 && plane % nv == 0 && vol % plane == 0 && vol / plane <= INT32_MAX && g_force_path.load(std::memory_order_relaxed) != 6) {
+            // z-paired and the planes divide into whole node ranges: the column-wise pack reads the table once
+            const int64_t D = vol / plane;
+            const int ZS = 16;
+            dim3 gz((unsigned)(plane / nv), (unsigned)((D + ZS - 1) / ZS), (unsigned)N);
+            if (gz.y <= 65535 && gz.z <= 65535) {
+                cs::pack_cl4_zcol<<<gz, 256, shm, s>>>(in, out, (int)C, (int)CP, plane, (int)D, ZS);
+                return launch_status();
+            }
+        }
         dim3 g((unsigned)((vol + nv - 1) / nv), (unsigned)N);
         cs::pack_cl4<<<g, 256, shm, s>>>(in, out, (int)C, (int)CP, vol, plane, slots);
         return launch_status();

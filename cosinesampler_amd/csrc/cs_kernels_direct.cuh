@@ -602,4 +602,59 @@ static __global__ __launch_bounds__(256) void pack_cl4(const float *__restrict__
     }
 }
 
+// The z-paired pack reading the table ONCE (round 3): a workgroup owns NV nodes of one (y, x) range and walks ZS z-planes
+// with two LDS tiles -- the plane it is writing rows for and the plane above it, which becomes the lower one of the next
+// step -- so every input element is read once (+1 plane per ZS) instead of twice by two different workgroups; the next
+// plane's loads are in flight while the current rows leave.  Needs plane % NV == 0.  grid (plane / NV, ceil(D / ZS), N).
+static __global__ __launch_bounds__(256) void pack_cl4_zcol(const float *__restrict__ in, float *__restrict__ out, int C, int CP,
+                                                     int64_t plane, int D, int ZS) {
+    extern __shared__ float tile[];   // [2][CP][LD]
+    const int NV = cl4_nv(CP) / 2, LD = NV + 4, CQ = CP >> 2, Q = NV / 4;
+    constexpr int MAXR = 8;           // float4 per thread and plane: CP * Q / 256 <= 8 for every CP <= 64 (CP * cl4_nv(CP) = 8192)
+    const int per = (CP * Q + 255) / 256;
+    const int n = blockIdx.z, z0 = blockIdx.y * ZS;
+    const int64_t v0 = (int64_t)blockIdx.x * NV, vol = plane * D;
+    const int z1 = min(z0 + ZS, D);
+    float4 R[MAXR];
+    auto issue = [&](int z) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            if (k < per) {
+                const int i = k * 256 + threadIdx.x, c = i / Q, v4 = i - c * Q;
+                R[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < CP * Q && c < C && z < D)
+                    R[k] = *reinterpret_cast<const float4 *>(in + ((int64_t)n * C + c) * vol + (int64_t)z * plane + v0 + 4 * v4);
+            }
+        }
+    };
+    auto stash = [&](float *t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            if (k < per) {
+                const int i = k * 256 + threadIdx.x, c = i / Q, v4 = i - c * Q;
+                if (i < CP * Q) *reinterpret_cast<float4 *>(t + c * LD + 4 * v4) = R[k];
+            }
+        }
+    };
+    float *cur = tile, *nxt = tile + CP * LD;
+    issue(z0);
+    stash(cur);
+    issue(z0 + 1);
+    for (int z = z0; z < z1; ++z) {
+        stash(nxt);
+        __syncthreads();
+        if (z + 1 < z1) issue(z + 2);
+        float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)n * vol + (int64_t)z * plane + v0) * 2 * CP);   // [node][slot][CP]
+        for (int i = threadIdx.x; i < NV * 2 * CQ; i += 256) {
+            const int v = i / (2 * CQ), r = i - v * (2 * CQ), slot = r / CQ, cq = r - slot * CQ;
+            const float *t = (slot ? nxt : cur) + (4 * cq) * LD + v;
+            dst[i] = make_float4(t[0], t[LD], t[2 * LD], t[3 * LD]);
+        }
+        __syncthreads();
+        float *sw = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+}
+
 }  // namespace cs

@@ -76,18 +76,21 @@ class GradReducer(object):
     def finish(self, out=None):
         if not self._pending:
             return out.zero_() if out is not None else None
-        total = out
-        first = True
-        for grad, work in self._pending:
+        for _, work in self._pending:
             if work is not None:
                 work.wait()            # stream-ordered for RCCL; blocks for gloo
-            if total is None:
-                total = grad.clone()
-            elif first and out is not None:
-                total.copy_(grad)
-            else:
-                total.add_(grad)
-            first = False
+        grads = [g for g, _ in self._pending]
+        if out is None:
+            total = grads[0].clone()
+            rest = grads[1:]
+        elif len(grads) == 1:
+            total = out.copy_(grads[0])
+            rest = []
+        else:                          # the first two summed straight into `out`: no copy pass over the buffer
+            total = torch.add(grads[0], grads[1], out=out)
+            rest = grads[2:]
+        for g in rest:
+            total.add_(g)
         self._pending = []
         if self.enabled and self.schedule == "once":
             all_reduce_grad_(total, self.group, async_op=False, even_alone=self.even_alone)

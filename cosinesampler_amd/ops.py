@@ -452,7 +452,7 @@ def sort_points(points, size, padding_mode=0, align_corners=True, multicell=True
 def force_path(mode):
     """Testing knob (cs_debug_force_path): 0 auto, 1 direct kernels only, 2 fast paths wherever they exist,
     3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 without the re-use of the sorted grad_output copy
-    between the stages of a step, 5 = 0 with the coherent-points hint ignored."""
+    between the stages of a step, 5 = 0 with the coherent-points hint ignored, 6 = 2 with the two-reads pack of 3D tables."""
     global _force_epoch, _force_mode
     _force_epoch += 1
     _force_mode = int(mode)

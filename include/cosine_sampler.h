@@ -85,8 +85,9 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * equal cell in registers and adds them to a private LDS image of the tile it is walking; the reference's per-sample
  * atomics, 2d.cu:464-505, :661-712, :850-888): no plan, no records, about a third of the time.  Results are the same for
  * ANY order of the points (up to the summation order of fp32 adds); a wrong hint only costs time -- an unordered set
- * empties its window at almost every sample.  cs_points_tile_changes measures an order.  Ignored where it does not apply
- * (3D, the forward, stages without grad_input, problems outside the 2D fast path). */
+ * empties its window at almost every sample.  cs_points_tile_changes measures an order.  Every 2D stage of the fast path
+ * has a coherent kernel (forward and the stages without grad_input included); ignored where it does not apply (3D, the
+ * second backward with grad_out_input, problems outside the 2D fast path). */
 #define CS_POINTS_COHERENT 0x8000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
@@ -193,7 +194,8 @@ void cs_debug_coherent_tuning(int samples_per_wave, int ablation_bits);
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
  * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 without the re-use of the sorted grad_output
- * copy between the stages of a step, 5 = as 0 but CS_POINTS_COHERENT is ignored (A/B of the hint).  Process-wide. */
+ * copy between the stages of a step, 5 = as 0 but CS_POINTS_COHERENT is ignored (A/B of the hint), 6 = as 2 but 3D tables
+ * are packed by the two-reads kernel instead of the column-wise one (A/B of cs_pack_input).  Process-wide. */
 void cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */

@@ -1204,3 +1204,32 @@ def test_integration_stub_from_the_document():
     assert_close(got[0], want[0], "stub third backward gInput")
     assert_close(got[1], want[1], "stub third backward ggOut")
 
+
+
+@pytest.mark.parametrize("N,C,D,H,W", [(2, 8, 19, 32, 16), (1, 4, 5, 32, 16), (3, 16, 17, 16, 16), (2, 6, 33, 32, 32),
+                                       (1, 8, 16, 64, 64)])
+def test_column_wise_z_paired_pack_is_the_layout(N, C, D, H, W):
+    """cs_pack_input for 3D tables: the column-wise kernel (one read of the table, round 3) against the layout it must
+    produce, built with torch -- node v holds [its own channel row | the row of the node one z-plane above, zeros past the
+    last plane], channels padded with zeros (cs_kernels_direct.cuh, pack_cl4) -- and against the two-reads kernel."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    inp = torch.rand(N, C, D, H, W, generator=g).to(DEV)
+    CP = min(c for c in (4, 8, 16, 32) if c >= C)          # cs_abi.hip cpad
+    nbytes = N * D * H * W * 2 * CP * 4
+    assert lib.cs_pack_bytes(3, N, C, D, H, W, 1 << 18) >= nbytes
+    cl = torch.zeros(N, D, H, W, 2, CP, device=DEV)
+    cl[..., 0, :C] = inp.permute(0, 2, 3, 4, 1)
+    cl[:, :-1, :, :, 1, :C] = inp.permute(0, 2, 3, 4, 1)[:, 1:]
+    got = {}
+    try:
+        for mode in (2, 6):
+            ops.force_path(mode)
+            buf = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=DEV)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.cs_pack_input(3, inp.data_ptr(), buf.data_ptr(), N, C, D, H, W, st), "cs_pack_input")
+            got[mode] = buf.view(torch.float32).view(N, D, H, W, 2, CP).clone()
+    finally:
+        ops.force_path(0)
+    assert torch.equal(got[2], cl), "column-wise pack differs from the z-paired layout"
+    assert torch.equal(got[6], cl), "two-reads pack differs from the z-paired layout"

@@ -136,6 +136,64 @@ __global__ __launch_bounds__(256) void write16(v4f *__restrict__ dst, int64_t n4
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) { v4f t = {1.f, 2.f, 3.f, (float)i}; __builtin_nontemporal_store(t, dst + i); }
 }
+
+// ---- round 3: what the coherent kernels' stream pattern can reach -------------------------------------------------
+__global__ __launch_bounds__(256) void write4_nt(float *__restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t plane = n / 16;
+    if (i < plane) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) __builtin_nontemporal_store((float)c, dst + (int64_t)c * plane + i);
+    }
+}
+// the same 16 planes, but a wave writes its 64 points as 4 instructions of 16 B per lane: 16 lanes per plane row
+__global__ __launch_bounds__(256) void write16_rows(float *__restrict__ dst, int64_t n) {
+    const int64_t plane = n / 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (p0 < plane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (lane >> 4) + 4 * i;
+            v4f t = {1.f, 2.f, 3.f, (float)row};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst + (int64_t)row * plane + p0 + 4 * (lane & 15)));
+        }
+    }
+}
+// a wave walks `chunk` consecutive points 64 at a time, DEPTH register sets of 16 plane loads in flight, one 8-byte
+// store per point: the coherent first backward without any of its work.  Launched with one wave per workgroup and `lds`
+// bytes of dynamic LDS to set the number of waves per CU.
+template <int DEPTH, bool WRITE16>
+__global__ __launch_bounds__(64) void stream_walk(const float *__restrict__ src, int64_t plane, int chunk, float *__restrict__ out,
+                                                  float *__restrict__ out16) {
+    extern __shared__ float lds_[];
+    const int lane = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    if (p0 >= plane) return;
+    float v[DEPTH][16];
+    auto issue = [&](float (&s)[16], int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s[c] = __builtin_nontemporal_load(src + (int64_t)c * plane + p0 + b + lane);
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(v[i], 64 * i);
+    for (int b0 = 0; b0 < chunk; b0 += 64 * DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            const int b = b0 + 64 * i;
+            float r = 0.f, q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { r += v[i][c]; q = fmaf(v[i][c], r, q); }
+            if (WRITE16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) __builtin_nontemporal_store(v[i][c] + r, out16 + (int64_t)c * plane + p0 + b + lane);
+            }
+            if (b + 64 * DEPTH < chunk) issue(v[i], b + 64 * DEPTH);
+            if (lds_[lane] == -1.f) r = 0.f;
+            reinterpret_cast<float2 *>(out)[p0 + b + lane] = make_float2(r, q);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void copy16(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) { v4f t = __builtin_nontemporal_load(src + i); __builtin_nontemporal_store(t, dst + i); }
@@ -327,6 +385,24 @@ int main(int argc, char **argv) {
     TIME("write4     1 GiB out, 4 B/lane sc1 stores (as the product outputs)", (write4<<<S / 256, 256>>>((float *)dst, S * 16)));
     TIME("write4p    1 GiB out, 4 B/lane plain stores", (write4_plain<<<S / 256, 256>>>((float *)dst, S * 16)));
     TIME("write16    1 GiB out, 16 B/lane nontemporal", (write16<<<n4 / 256, 256>>>(dst, n4)));
+    TIME("write4nt   1 GiB out, 4 B/lane nontemporal stores (the coherent kernels' outputs)", (write4_nt<<<S / 256, 256>>>((float *)dst, S * 16)));
+    TIME("write16r   1 GiB out, the same 16 planes, 16 B/lane nontemporal: a wave's 64 points as 4 x (4 rows x 256 B)", (write16_rows<<<S / 256, 256>>>((float *)dst, S * 16)));
+    {
+        float *o2; CK(hipMalloc(&o2, S * 8));
+        CK(hipFuncSetAttribute((const void *)stream_walk<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        CK(hipFuncSetAttribute((const void *)stream_walk<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        CK(hipFuncSetAttribute((const void *)stream_walk<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        const int chunk = 512;
+        TIME("walk d2 11w  1 GiB in + 128 MiB out: wave walks 512 points, 2 sets in flight, 13.9 KiB LDS (11 waves/CU)", (stream_walk<2, false><<<S / chunk, 64, 14240>>>((const float *)src, S, chunk, o2, nullptr)));
+        TIME("walk d4 11w  the same, 4 sets in flight", (stream_walk<4, false><<<S / chunk, 64, 14240>>>((const float *)src, S, chunk, o2, nullptr)));
+        TIME("walk d2 16w  2 sets, 10 KiB LDS (16 waves/CU)", (stream_walk<2, false><<<S / chunk, 64, 10240>>>((const float *)src, S, chunk, o2, nullptr)));
+        TIME("walk d2 32w  2 sets, 4 KiB LDS (registers bound the waves)", (stream_walk<2, false><<<S / chunk, 64, 4096>>>((const float *)src, S, chunk, o2, nullptr)));
+        TIME("walk d2 11w 2k  2 sets, 11 waves/CU, 2048 points per wave", (stream_walk<2, false><<<S / 2048, 64, 14240>>>((const float *)src, S, 2048, o2, nullptr)));
+        TIME("walkw d2 11w  1 GiB in + 1 GiB out (16 dword stores per point) + 128 MiB, 11 waves/CU", (stream_walk<2, true><<<S / chunk, 64, 14240>>>((const float *)src, S, chunk, o2, (float *)dst)));
+        TIME("walkw d2 32w  the same, 4 KiB LDS", (stream_walk<2, true><<<S / chunk, 64, 4096>>>((const float *)src, S, chunk, o2, (float *)dst)));
+        CK(hipFree(o2));
+    }
+    if (argc > 1 && !strcmp(argv[1], "walk")) return 0;
     TIME("copy16     1 GiB in + 1 GiB out", (copy16<<<n4 / 256, 256>>>(src, dst, n4)));
     {
         const int64_t gpn = P * 4 / 256;
