@@ -26,6 +26,9 @@ elif [ "$1" = run ]; then
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 print("%-16s step %.3f ms | " % (sys.argv[1], j["ms_per_step"]) + "  ".join("%s %.3f" % (k[:9], v) for k, v in j["stages_ms"].items()), flush=True)
+p = j.get("presorted_points")
+if p:
+    print("%-16s   ordered points %.3f ms | " % ("", p["ms_per_step"]) + "  ".join("%s %.3f" % (k[:9], v) for k, v in p["stages_ms"].items()), flush=True)
 PY
   done
 fi
