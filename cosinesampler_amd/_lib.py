@@ -30,10 +30,10 @@ _STAGES = {
 EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_streams_supported", "cs_pack_bytes", "cs_pack_input",
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path",
             "cs2d_plan_keeps_sorted_copy", "cs_sort_points_bytes", "cs2d_sort_points", "cs3d_sort_points",
-            "cs_points_tile_changes", "cs_debug_coherent_tuning"]
+            "cs_points_tile_changes", "cs_points_tile_changes_sampled", "cs_debug_coherent_tuning"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
 GRID_BROADCAST = 0x4000                   # CS_GRID_BROADCAST, OR-ed into `kernel` / the plan builders' `flags`
@@ -89,6 +89,8 @@ def load():
     lib.cs3d_sort_points.argtypes = [_c_f, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 3 + [_c_f, _c_sz, _c_f]
     lib.cs_points_tile_changes.restype = _c_int
     lib.cs_points_tile_changes.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 3 + [_c_f]
+    lib.cs_points_tile_changes_sampled.restype = _c_int
+    lib.cs_points_tile_changes_sampled.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 4 + [_c_f]
     lib.cs_debug_coherent_tuning.restype = None
     lib.cs_debug_coherent_tuning.argtypes = [_c_int, _c_int]
     if lib.cs_abi_version() != ABI_VERSION:

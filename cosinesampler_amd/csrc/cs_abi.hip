@@ -1140,6 +1140,12 @@ int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_
                                         (hipStream_t)stream);
 }
 
+int cs_points_tile_changes_sampled(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
+                                   int padding_mode, int align_corners, int multicell, int segments, void *stream) {
+    return cs::sort::sample_tile_changes(dim, points, P, D, H, W, padding_mode, align_corners, multicell, segments, count,
+                                         (hipStream_t)stream);
+}
+
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;

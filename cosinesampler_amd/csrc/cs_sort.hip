@@ -72,6 +72,24 @@ __global__ __launch_bounds__(256) void tile_changes(const float *__restrict__ pt
     }
 }
 
+// the same count over `segments` runs of 1024 consecutive points, seg_stride points apart (a run's first point has no
+// predecessor inside the run and counts as no change): a prefix says nothing about the rest of the set
+__global__ __launch_bounds__(256) void tile_changes_sampled(const float *__restrict__ pts, int64_t P, KeyDims k,
+                                                            int64_t seg_stride, uint32_t *__restrict__ count) {
+    __shared__ uint32_t wsum[4];
+    const int64_t p = (int64_t)(blockIdx.x >> 2) * seg_stride + (int64_t)(blockIdx.x & 3) * 256 + threadIdx.x;
+    const bool first = (blockIdx.x & 3) == 0 && threadIdx.x == 0;
+    bool change = false;
+    if (p < P && !first) change = cell_key(pts + p * k.dim, k, true) != cell_key(pts + (p - 1) * k.dim, k, true);
+    const uint64_t m = __ballot(change);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(count, t);
+    }
+}
+
 int key_dims(KeyDims &k, int dim, int64_t D, int64_t H, int64_t W, int pad, int align, int multicell) {
     if ((dim != 2 && dim != 3) || H < 1 || W < 1 || (dim == 3 && D < 1) || pad < 0 || pad > 2) return -1;
     if (W > (1 << 28) || H > (1 << 28) || D > (1 << 28)) return -2;
@@ -143,6 +161,21 @@ int count_tile_changes(int dim, const float *points, int64_t P, int64_t D, int64
     if (!count || (P > 0 && !points)) return -1;
     zero_word<<<1, 1, 0, stream>>>(count);
     if (P > 0) tile_changes<<<(unsigned)((P + 255) / 256), 256, 0, stream>>>(points, P, k, count);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int sample_tile_changes(int dim, const float *points, int64_t P, int64_t D, int64_t H, int64_t W, int padding_mode,
+                        int align_corners, int multicell, int segments, uint32_t *count, hipStream_t stream) {
+    if (segments < 1 || segments > 65536) return -1;
+    if (P <= (int64_t)segments * 1024)      // the whole set is no more than the sample would be
+        return count_tile_changes(dim, points, P, D, H, W, padding_mode, align_corners, multicell, count, stream);
+    KeyDims k;
+    int rc = key_dims(k, dim, D, H, W, padding_mode, align_corners, multicell);
+    if (rc) return rc;
+    if (!count || !points) return -1;
+    zero_word<<<1, 1, 0, stream>>>(count);
+    tile_changes_sampled<<<(unsigned)(4 * segments), 256, 0, stream>>>(points, P, k, P / segments, count);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

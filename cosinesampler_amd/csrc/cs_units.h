@@ -44,5 +44,7 @@ int sort_points(int dim, const float *points, int64_t P, int64_t D, int64_t H, i
 // fraction-of-coherence measure: number of times the tile of consecutive points changes, per table 0
 int count_tile_changes(int dim, const float *points, int64_t P, int64_t D, int64_t H, int64_t W, int padding_mode,
                        int align_corners, int multicell, uint32_t *count /* device, one word */, hipStream_t stream);
+int sample_tile_changes(int dim, const float *points, int64_t P, int64_t D, int64_t H, int64_t W, int padding_mode,
+                        int align_corners, int multicell, int segments, uint32_t *count, hipStream_t stream);
 }  // namespace sort
 }  // namespace cs

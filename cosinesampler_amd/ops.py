@@ -374,7 +374,7 @@ def points_order(mode=None):
     return _points_order
 
 
-ORDER_SAMPLE_POINTS = 1 << 16      # the order is judged on this many leading points (a 5 us kernel)
+ORDER_SAMPLE_SEGMENTS = 64         # the order is judged on this many runs of 1024 consecutive points spread over the set (a 5 us kernel)
 
 
 def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream):
@@ -389,7 +389,7 @@ def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, mu
         # decision, measurement in flight?, device word, pinned host word, event
         st = _order_state[sig] = [False, False, torch.empty(1, dtype=torch.int32, device=grid.device),
                                   torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event()]
-    Pm = min(P, ORDER_SAMPLE_POINTS)
+    Pm = min(P, ORDER_SAMPLE_SEGMENTS * 1024)
     if st[1] and st[4].query():       # the measurement in flight has arrived
         st[0] = int(st[3].item()) * 256 <= Pm
         st[1] = False
@@ -398,9 +398,9 @@ def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, mu
     # stale 'coherent' costs an unordered call 20-40x its time (13-17 ms per stage at BASELINE configs[1], measured) --
     # so the lag is kept as short as not synchronising allows.
     if not st[1] and not torch.cuda.is_current_stream_capturing():
-        _lib.check(lib.cs_points_tile_changes(2, grid.data_ptr(), st[2].data_ptr(), Pm, 1, shape[-2], shape[-1],
-                                              int(padding_mode), int(bool(align_corners)), int(bool(multicell)), stream),
-                   "cs_points_tile_changes")
+        _lib.check(lib.cs_points_tile_changes_sampled(2, grid.data_ptr(), st[2].data_ptr(), P, 1, shape[-2], shape[-1],
+                                                      int(padding_mode), int(bool(align_corners)), int(bool(multicell)),
+                                                      ORDER_SAMPLE_SEGMENTS, stream), "cs_points_tile_changes_sampled")
         st[3].copy_(st[2], non_blocking=True)
         st[4].record()
         st[1] = True

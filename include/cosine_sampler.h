@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 9
+#define CS_ABI_VERSION 10
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -186,6 +186,12 @@ int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, i
                      void *stream);
 int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
                            int padding_mode, int align_corners, int multicell, void *stream);
+/* The same count taken on a SAMPLE: `segments` (1..65536) runs of 1024 consecutive points spread evenly over the set (all
+ * of it when P <= 1024 * segments) -- a few microseconds whatever P is, and unlike a prefix it sees every part of the set.
+ * The hint pays when changes * 256 <= min(P, 1024 * segments). */
+int cs_points_tile_changes_sampled(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H,
+                                   int64_t W, int padding_mode, int align_corners, int multicell, int segments,
+                                   void *stream);
 /* Tuning / experiments on the coherent kernels: samples_per_wave (a multiple of 64; 0 keeps the value) and ablation_bits,
  * which switch parts of the kernels OFF to see what each costs (results are then wrong): 1 no scatter-reduce, 2 no window
  * flush, 4 no products / outputs; 0 = the product.  Process-wide. */
