@@ -171,13 +171,15 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=F
     return e0.elapsed_time(e1) / steps
 
 
-def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None, warm_plan=False):
+def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None, warm_plan=False, sort_points=False):
     """forward + the three backward stages on synthetic inputs of the given shape (any of BASELINE.json's configs or
     the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step)."""
     from cosinesampler_amd import multicell_offset, ops
     g = torch.Generator(device="cpu").manual_seed(11)
     cells = torch.rand((N, C) + (size,) * dim, generator=g).to(dev)
     pts = (torch.rand(P, dim, generator=g) * 2 - 1).to(dev)
+    if sort_points:          # a fixed point set ordered once by cell (ops.sort_points), as in the 2D headline's presorted_points
+        pts, _ = ops.sort_points(pts, (size,) * dim)
     grid = pts.view((1,) * dim + (P, dim)).repeat((N,) + (1,) * (dim + 1)).contiguous()
     oshape = (N, C) + (1,) * (dim - 1) + (P,)
     gOut = torch.randn(oshape, generator=g).to(dev)
@@ -445,6 +447,10 @@ def main():
                     line[key]["vs_two_32_channel_steps"] = ms_o / (2 * line["channels_32"]["ms_per_step"])
                 if key == "config_3d":     # fixed collocation points: the plan of the (same) grid tensor kept across steps
                     line[key]["ms_per_step_warm_plan"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, warm_plan=True)[0]
+                    # the same kernels on the same points in cell order (ops.sort_points, 3D): gathers and row fetches of
+                    # neighbouring samples share lines
+                    line[key]["ms_per_step_sorted_points"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, sort_points=True)[0]
+                    line[key]["ms_per_step_sorted_points_warm_plan"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, warm_plan=True, sort_points=True)[0]
             ms_h, s_h = stage_pipeline_ms(dev, 2, N, C, H, P, 0, stream_dtype=torch.bfloat16)
             line["bf16_streams"] = {"ms_per_step": ms_h, "Msamples_per_s": s_h / ms_h / 1e3,
                                     "what": "the headline step with output / grad_output / grad_grad_out / grad_out_ggout "
