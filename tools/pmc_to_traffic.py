@@ -19,7 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % tag, "*", "*counter_collection.csv"))):
+def newest(pattern):
+    """one CSV per pass directory: gpurun merges a new run's files next to those of earlier runs"""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(os.path.dirname(f))
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return [by_dir[d] for d in sorted(by_dir)]
+
+
+for f in newest(os.path.join(ROOT, "gpurun_out", "pmc_%s_[0-9]*" % tag, "*", "*counter_collection.csv")):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -47,7 +57,8 @@ json.dump(summ, open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag)
 def total(prefixes, field):
     t = 0.0
     for pre in prefixes:
-        hit = [v for k, v in summ.items() if k.startswith(pre)]
+        # "name$": that kernel only; otherwise every kernel whose name starts so (the plan's scan kernels, template arguments)
+        hit = [v for k, v in summ.items() if (k == pre[:-1] if pre.endswith("$") else k.startswith(pre))]
         if not hit:
             print("warning: no kernel named", pre, file=sys.stderr)
         for v in hit:
@@ -59,19 +70,19 @@ T = 16 * 16 * 256 * 256 * 4      # the zero-fill of one grad_input (the launches
 plan = ["cs::tiled::plan_count", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiled::plan_scatter",
         "cs::tiled::plan_tile_sort"]
 stages = {
-    "forward": ["cs::pack_cl4", "cs::tiled::point_forward<0, 4, float>"],
+    "forward": ["cs::pack_cl4$", "cs::tiled::point_forward<0, 4, float>"],
     "plan": plan,   # built once per step, used by the three backward stages (bench.py times it as its own span)
     "backward": ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
     "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
     # the headline step on ORDERED points (bench.py presorted_points): coherent kernels, no plan; each scatter stage also
     # clears a channels-last accumulator (zero_fill, T bytes written) and unpacks it (cs::unpack_cl4)
-    "ordered_forward": ["cs::pack_cl4", "cs::coh::stage<0, 4, 0, false, true, float>"],
+    "ordered_forward": ["cs::pack_cl4$", "cs::coh::stage<0, 4, 0, false, true, float>"],
     "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float>", "cs::unpack_cl4"],
     "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float>", "cs::unpack_cl4"],
     "ordered_bbb_fused": ["cs::coh::stage<0, 4, 3, true, true, float>", "cs::unpack_cl4"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
-    "3d_forward": ["cs::pack_cl4", "cs::cl::forward<3, 2, 2, float>"],
+    "3d_forward": ["cs::pack_cl4_zcol", "cs::cl::forward<3, 2, 2, float>"],
     "3d_plan": ["cs::tiles3::plan_count3t", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiles3::plan_scatter3t"],
     "3d_backward": ["cs::cl::backward<3, 2, 2, 2, float>", "cs::tiles3::tile3_scatter<2, 0>"],
     "3d_backward_backward": ["cs::cl::backward_backward<3, 2, 2, false, 2, float>", "cs::tiles3::tile3_scatter<2, 1>"],
@@ -92,7 +103,7 @@ for st, ks in stages.items():
 # the Helmholtz step (tools/helmholtz_profile.py under --pmc, 4 steps): every kernel of the process, ours and torch's
 helm = {"ours": collections.defaultdict(float), "torch": collections.defaultdict(float)}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_helm_%s" % (tag, c), "*", "*counter_collection.csv"))):
+    for f in newest(os.path.join(ROOT, "gpurun_out", "pmc_%s_helm_%s" % (tag, c), "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             who = "ours" if ("cs::" in k or "zero_fill" in k or "_ZN2cs" in k) else "torch"
