@@ -331,8 +331,16 @@ struct Args {
 // `dbg`: experiments only (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window flush, 4 no per-sample products,
 // 32 no table-window loads, 64 no scatter operands written to LDS.
 // =====================================================================================================
-template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST>
-__global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Flags f, int chunk, int dbg) {
+// COMMON: zeros padding with align_corners -- every BASELINE config and the reference's defaults -- as compile-time
+// constants: the padding variants are wave-uniform branches, but they cost scalar registers (the general kernels spill them
+// to vector lanes), scalar instructions and ~40 branches per batch in kernels that are instruction-issue bound.
+template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST, bool COMMON = false>
+__global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
+    Flags f = f_;
+    if constexpr (COMMON) {
+        f.pad = PAD_ZEROS;
+        f.align = 1;
+    }
     constexpr int C = 4 * CQ;
     using L = Lay<C>;
     constexpr bool IN = MODE != FWD;                     // reads the cotangent stream gOut

@@ -62,6 +62,17 @@ template <int MODE, bool TWO, bool SCAT = true>
 int launch(const Launch &L, const Args &a) {
     const Geometry g = geometry(L);
     int rc = 0;
+#ifndef CS_COH_NO_COMMON
+    if (L.sdt == 0 && L.f.pad == PAD_ZEROS && L.f.align) {     // fp32 streams, zeros padding, align_corners: the specialised kernels
+        COH_KERNEL_(L.kernel, COH_CQ(L.cq, {
+            using ST = float;
+            const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
+            rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true>, shm);
+            if (!rc) stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true><<<g.grid, g.block, shm, L.stream>>>(a, L.d, L.f, g.chunk, g.dbg);
+        }));
+        return rc ? rc : status();
+    }
+#endif
     COH_KERNEL(L, COH_CQ(L.cq, {
         const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
         rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST>, shm);
