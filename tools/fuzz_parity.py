@@ -71,7 +71,7 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
 bad = 0
 for case in range(cases):
     d = rng.choice([2, 2, 3])
-    C = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 31, 32, 33] if d == 2 else [1, 2, 3, 4, 5, 6, 8, 12, 16, 17])
+    C = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 31, 32, 33, 48, 70] if d == 2 else [1, 2, 3, 4, 5, 6, 8, 12, 16, 17, 24, 40])
     N = rng.choice([1, 2, 3, 5])
     sp = tuple(rng.choice([2, 3, 5, 16, 17, 18, 33, 40]) for _ in range(d)) if d == 2 else \
         tuple(rng.choice([2, 3, 5, 8, 9, 16]) for _ in range(d))
@@ -81,6 +81,10 @@ for case in range(cases):
     shared = rng.choice([True, False])
     bc = N > 1 and rng.random() < 0.25
     spread = rng.choice([0.9, 1.0, 1.3])
+    # round 3: the order of the points (as drawn / in cell order / blocks of the ordered set shuffled) and how the op is told
+    # about it (the hint forced either way, or left to the op's own measurement); only the time may depend on either
+    order = rng.choice(["drawn", "drawn", "sorted", "sorted", "half"])
+    hint = rng.choice(["auto", "coherent", "random"])
     if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
         continue                      # (every random draw of the case is above: case k is the same problem as in a full run)
     g = torch.Generator().manual_seed(seed * 100003 + case)
@@ -89,6 +93,15 @@ for case in range(cases):
     if P >= 3:
         grid.view(N, P, d)[:, 0] = -1.0
         grid.view(N, P, d)[:, 1] = 1.0
+    if order != "drawn" and P >= 2:
+        for n in range(N):              # every table's point set ordered by cell (table 0's cells: the multicell shift is < 1 cell)
+            srt, _ = ops.sort_points(grid.view(N, P, d)[n].contiguous().to(DEV), sp, pad, align, mc)
+            srt = srt.cpu()
+            if order == "half":
+                nb = min(P, 7)
+                bounds = [P * i // nb for i in range(nb + 1)]
+                srt = torch.cat([srt[bounds[b]:bounds[b + 1]] for b in torch.randperm(nb, generator=g).tolist()])
+            grid.view(N, P, d)[n] = srt
     osh = (N, C) + (1,) * (d - 1) + (P,)
     t = dict(inp=inp, grid=grid, gOut=torch.randn(osh, generator=g), cI=torch.randn(inp.shape, generator=g),
              cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g), hO=torch.randn(osh, generator=g))
@@ -96,11 +109,13 @@ for case in range(cases):
     SCALE.clear()
     want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc)
     ops.force_path(force)
+    ops.points_order(hint)
     try:
         got = run(ops, t, off, pad, align, ke, mc, DEV, shared, bc)
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)
+        ops.points_order("auto")
     errs = {k: rel(got[k], want[k], SCALE.get(k, 0.0)) for k in want}
     if os.environ.get("FUZZ_ONLY") or os.environ.get("FUZZ_DETAIL") == str(case):
         for k in want:
@@ -111,10 +126,10 @@ for case in range(cases):
     worst = max(errs, key=errs.get)
     if not all(torch.isfinite(v).all() for v in got.values()) or errs[worst] > 1e-5:
         bad += 1
-        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s bc=%s -> %s %.3e"
-              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, bc, worst, errs[worst]), flush=True)
+        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s bc=%s order=%s hint=%s -> %s %.3e"
+              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, bc, order, hint, worst, errs[worst]), flush=True)
     elif case % 25 == 0:
-        print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d) worst %s %.1e" % (case, d, C, sp, P, force, worst, errs[worst]),
+        print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d %s/%s) worst %s %.1e" % (case, d, C, sp, P, force, order, hint, worst, errs[worst]),
               flush=True)
 print("%d cases, %d failures" % (cases, bad))
 sys.exit(1 if bad else 0)
