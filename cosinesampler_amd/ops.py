@@ -255,6 +255,7 @@ class StepContext(object):
             for i, e in enumerate(_plan_cache):              # a plan of this very grid from an earlier step
                 if e.cfg == cfg and e.of.same(grid):
                     pe = e
+                    pe.sorted_go = None      # ... but never that step's sorted grad_output copy: a new step, new cotangents
                     _plan_cache.insert(0, _plan_cache.pop(i))
                     break
         if pe is None:
