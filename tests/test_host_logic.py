@@ -229,3 +229,78 @@ def test_broadcast_grid_through_the_function_chain(monkeypatch, d):
         res.append((out.detach(), u_g.detach(), u_gg.detach(), gc))
     for a, b in zip(*res):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_held_identity_is_the_object_not_the_address():
+    """ops._Held (round 3): what a cached plan / channels-last copy / sorted grad_output copy is remembered by.  Equal
+    address + shape + version is NOT an identity once the tensor is gone; while it is held the address cannot be re-used,
+    and an alias of the held memory (a view with the same layout) is the same bytes."""
+    from cosinesampler_amd import ops
+    a = torch.rand(4, 8, 1, 50)
+    h = ops._Held(a)
+    assert h.same(a)
+    assert h.same(a.view(4, 8, 1, 50))                    # an alias of the very same memory
+    assert not h.same(a.clone())                          # other memory
+    assert not h.same(a[:2])                              # other shape
+    a.add_(1.0)                                           # in-place update: another version
+    assert not h.same(a)
+    assert ops._Held(None).same(None) and not ops._Held(None).same(a) and not h.same(None)
+    # the failure the strong reference prevents: free the tensor, allocate an equal one -- the allocator may hand out the
+    # same block with version 0 again; a _Held of the FIRST tensor still says no (it holds it, so the block is not re-used)
+    b = torch.rand(4, 8, 1, 50)
+    hb = ops._Held(b)
+    ptr = b.data_ptr()
+    del b
+    c = torch.rand(4, 8, 1, 50)
+    assert c.data_ptr() != ptr and not hb.same(c)
+
+
+def test_channel_groups_cover_every_channel_once():
+    """ops._channel_groups: tables wider than the fast paths run as ranges of at most 32 (2D) / 16 (3D) channels."""
+    from cosinesampler_amd import ops
+    for dim, cap in ((2, 32), (3, 16)):
+        for C in (1, cap - 1, cap):
+            assert ops._channel_groups(torch.empty((2, C) + (4,) * dim), dim) is None
+        for C in (cap + 1, 2 * cap, 2 * cap + 7, 5 * cap):
+            groups = ops._channel_groups(torch.empty((2, C) + (4,) * dim), dim)
+            assert groups[0][0] == 0 and groups[-1][1] == C
+            assert all(b - a <= cap and b > a for a, b in groups)
+            assert all(groups[i][1] == groups[i + 1][0] for i in range(len(groups) - 1))
+
+
+def test_order_and_cache_knobs_validate_their_arguments():
+    from cosinesampler_amd import ops
+    assert ops.points_order() in ("auto", "coherent", "random")
+    with pytest.raises(ValueError):
+        ops.points_order("sorted")
+    try:
+        assert ops.points_order("random") == "random" and ops.points_order() == "random"
+    finally:
+        ops.points_order("auto")
+    assert ops.plan_cache() == 0
+    try:
+        assert ops.plan_cache(3) == 3 and ops.plan_cache(-5) == 0
+    finally:
+        ops.plan_cache(0)
+
+
+def test_grad_reducer_sums_locally_without_a_process_group():
+    """dist.GradReducer with no process group: both schedules only add the pushed gradients up -- into `out` without a
+    copy pass when there are two or more -- and an empty reducer zeroes `out`."""
+    from cosinesampler_amd.dist import GradReducer
+    g = [torch.rand(3, 5) for _ in range(3)]
+    for schedule in ("per_stage", "once"):
+        for k in (1, 2, 3):
+            r = GradReducer(schedule=schedule)
+            for t in g[:k]:
+                r.push(t)
+            out = torch.full((3, 5), 7.0)
+            tot = r.finish(out=out)
+            assert tot is out and torch.allclose(out, sum(g[:k]))
+            r2 = GradReducer(schedule=schedule)
+            for t in g[:k]:
+                r2.push(t)
+            assert torch.allclose(r2.finish(), sum(g[:k]))
+        assert torch.equal(GradReducer(schedule=schedule).finish(out=torch.ones(2)), torch.zeros(2))
+    with pytest.raises(ValueError):
+        GradReducer(schedule="sometimes")
