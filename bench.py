@@ -109,12 +109,12 @@ def cpu_baseline(N, C, H, seconds_budget=20.0):
                       "N=%d C=%d H=W=%d P=%d (%d samples) in %.2f s on %d threads" % (N, C, H, P, S, t, cores)}
 
 
-def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=False, grid_leaf=False):
+def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=False, grid_leaf=False, summed_op=False):
     """BASELINE.json configs[2]: the PIXEL-style Helmholtz step driven entirely by torch.autograd
     (reference test/test_2d.py pattern): u = MLP(sum_n sampler(cells, grid)); u_x, u_y; u_xx, u_yy via the
     second backward; loss = mean((u_xx + u_yy + k^2 u)^2); d loss / d cells via the third backward.
     Returns average milliseconds per step (HIP events), first step excluded."""
-    from cosinesampler_amd import CosineSampler2d
+    from cosinesampler_amd import CosineSampler2d, CosineSampler2dSum
     g = torch.Generator(device="cpu").manual_seed(7)
     cells = torch.rand(N, C, H, H, generator=g).to(dev).requires_grad_(True)
     W1 = (torch.randn(16, C, generator=g) * 0.5).to(dev)
@@ -148,10 +148,13 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=F
         if grid_leaf:
             return one_leaf()
         grid = torch.cat([x, y], -1).view(1, 1, P, 2)
-        if not broadcast_grid:            # the reference pattern (test/test_2d.py:38); broadcast_grid: the same points
-            grid = grid.repeat(N, 1, 1, 1)   # handed over once, CS_GRID_BROADCAST (not expressible with the reference op)
-        val = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
-        u = torch.tanh(val.sum(0).view(C, -1).t() @ W1.t()) @ W2.t()
+        if summed_op:                     # sampler(...).sum(0) as ONE op (CosineSampler2dSum, CS_SUM_OVER_N): no (N,C,P) tensor at all
+            feat = CosineSampler2dSum.apply(cells, grid, "zeros", True, "cosine", True)[0]
+        else:
+            if not broadcast_grid:            # the reference pattern (test/test_2d.py:38); broadcast_grid: the same points
+                grid = grid.repeat(N, 1, 1, 1)   # handed over once, CS_GRID_BROADCAST (not expressible with the reference op)
+            feat = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True).sum(0)
+        u = torch.tanh(feat.view(C, -1).t() @ W1.t()) @ W2.t()
         u_x, u_y = torch.autograd.grad(u, (x, y), ones, create_graph=True)
         (u_xx,) = torch.autograd.grad(u_x, x, ones, create_graph=True)
         (u_yy,) = torch.autograd.grad(u_y, y, ones, create_graph=True)
@@ -518,6 +521,13 @@ def main():
             line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points"] = helmholtz_step(N, C, H, P, dev, sort_points=True)
             line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points_broadcast_grid"] = helmholtz_step(
                 N, C, H, P, dev, broadcast_grid=True, sort_points=True)
+            line["pixel_helmholtz_autograd"]["ms_per_step_sorted_points_summed_op"] = helmholtz_step(
+                N, C, H, P, dev, sort_points=True, summed_op=True)
+            line["pixel_helmholtz_autograd"]["ms_per_step_summed_op"] = helmholtz_step(N, C, H, P, dev, summed_op=True)
+            line["pixel_helmholtz_autograd"]["summed_op"] = (
+                "the same step with features = CosineSampler2dSum.apply(cells, points) instead of "
+                "CosineSampler2d.apply(cells, points.repeat(N,1,1,1)).sum(0): on ordered points the summing kernels (CS_SUM_OVER_N) "
+                "run and no (N,C,P) tensor exists anywhere in the step; on drawn points the plain op and torch sums do the work")
             from cosinesampler_amd import ops as _ops
             _ops.plan_cache(1)
             try:

@@ -30,13 +30,14 @@ _STAGES = {
 EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_streams_supported", "cs_pack_bytes", "cs_pack_input",
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path",
             "cs2d_plan_keeps_sorted_copy", "cs_sort_points_bytes", "cs2d_sort_points", "cs3d_sort_points",
-            "cs_points_tile_changes", "cs_points_tile_changes_sampled", "cs_debug_coherent_tuning"]
+            "cs_points_tile_changes", "cs_points_tile_changes_sampled", "cs_debug_coherent_tuning", "cs2d_sum_over_n_supported"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
 GRID_BROADCAST = 0x4000                   # CS_GRID_BROADCAST, OR-ed into `kernel` / the plan builders' `flags`
+SUM_OVER_N = 0x10000                      # CS_SUM_OVER_N, OR-ed into `kernel` with GRID_BROADCAST: per-point results summed over the tables
 POINTS_COHERENT = 0x8000                  # CS_POINTS_COHERENT, OR-ed into `kernel`: consecutive points share cells (a hint)
 STAGE_POINTS_COHERENT = 0x20              # CS_STAGE_POINTS_COHERENT, OR-ed into the stage id of cs_workspace_bytes
 STAGE_ID = {"forward": 0, "backward": 1, "backward_backward": 2, "backward_backward_backward": 3, "bbb_fused": 3}
@@ -89,6 +90,8 @@ def load():
     lib.cs3d_sort_points.argtypes = [_c_f, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 3 + [_c_f, _c_sz, _c_f]
     lib.cs_points_tile_changes.restype = _c_int
     lib.cs_points_tile_changes.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 3 + [_c_f]
+    lib.cs2d_sum_over_n_supported.restype = _c_int
+    lib.cs2d_sum_over_n_supported.argtypes = [_c_i64] * 5 + [_c_int] * 2
     lib.cs_points_tile_changes_sampled.restype = _c_int
     lib.cs_points_tile_changes_sampled.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 4 + [_c_f]
     lib.cs_debug_coherent_tuning.restype = None

@@ -29,6 +29,7 @@ struct Problem {
     int kernel;
     int sdt;      // element type of the channel-major streams: 0 fp32, 1 half, 2 bfloat16 (CS_STREAM_*)
     bool coherent;   // CS_POINTS_COHERENT: the caller says consecutive points share cells
+    bool sum_n;      // CS_SUM_OVER_N: shared points and cotangents, per-point results summed over the tables
     hipStream_t stream;
     unsigned blocks;
 };
@@ -41,7 +42,9 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.sdt = (kernel & CS_STREAM_F16) ? 1 : (kernel & CS_STREAM_BF16) ? 2 : 0;
     const bool grid_bc = (kernel & CS_GRID_BROADCAST) != 0;
     pb.coherent = (kernel & CS_POINTS_COHERENT) != 0;
-    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST | CS_POINTS_COHERENT);
+    pb.sum_n = (kernel & CS_SUM_OVER_N) != 0;
+    if (pb.sum_n && (!grid_bc || exact)) return CS_ERR_UNSUPPORTED;     // one set of points for every table; the reference's derivatives
+    kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST | CS_POINTS_COHERENT | CS_SUM_OVER_N);
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
     // node indices and sizes are kept in 32-bit registers; element offsets are 64-bit
     if (N > INT32_MAX || C > INT32_MAX || D > (1 << 28) || H > (1 << 28) || W > (1 << 28)) return CS_ERR_UNSUPPORTED;
@@ -497,12 +500,15 @@ size_t point_lds(int C) { return (size_t)4 * (tl::REC_FLOATS + C * tl::OUT_LD) *
 
 cs::coh::Launch coh_launch(const Problem &pb);
 bool coherent_applies(const Problem &pb);
+int sum_n_check(const Problem &pb, bool has_gOut, bool has_hO);
 
 int tiled_forward(const Problem &pb, const float *input, const float *grid, const float *offset, float *output,
                   const float *input_cl, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
-    int rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
+    int rc = sum_n_check(pb, false, false);
+    if (rc) return rc;
+    rc = prepare(pb, CS_STAGE_FORWARD, input, grid, offset, input_cl, nullptr, ws, pr);
     if (rc) return rc;
     if (coherent_applies(pb)) return cs::coh::forward(coh_launch(pb), pr.icl, grid, offset, output);
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_forward<KERNEL, CQ, ST><<<point_grid(pb), kBlock, point_lds((int)cpad(pb.d.C)), pb.stream>>>(
@@ -519,10 +525,20 @@ cs::coh::Launch coh_launch(const Problem &pb) {
     L.sdt = pb.sdt;
     L.cq = (int)(cpad(pb.d.C) / 4);
     L.stream = pb.stream;
+    L.nsum = pb.sum_n;
     return L;
 }
+// CS_SUM_OVER_N lives on the coherent kernels alone (whatever the order of the points: only their speed depends on it)
 bool coherent_applies(const Problem &pb) {
+    if (pb.sum_n) return true;
     return pb.coherent && g_force_path.load(std::memory_order_relaxed) != 5 && cs::coh::supported(coh_launch(pb));
+}
+// ... for the shapes and flags the summing kernels are built for; the shared cotangents have no n-stride
+int sum_n_check(const Problem &pb, bool has_gOut, bool has_hO) {
+    if (!pb.sum_n) return CS_OK;
+    if (!cs::coh::supported_nsum(coh_launch(pb))) return CS_ERR_UNSUPPORTED;
+    if ((has_gOut && pb.d.go_ns != 0) || (has_hO && pb.d.ho_ns != 0)) return CS_ERR_INVALID;
+    return CS_OK;
 }
 // the zeroed channels-last accumulator the coherent kernels add into
 int coherent_accumulator(const Problem &pb, Carve &ws, float *&acc) {
@@ -542,7 +558,9 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     Prepared pr;
     // without grad_input nothing is scattered: no plan, no fat rows -- the point kernel gathers and is all there is
     const bool coh = coherent_applies(pb);
-    int rc = prepare(pb, grad_input && !coh ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
+    int rc = sum_n_check(pb, true, false);
+    if (rc) return rc;
+    rc = prepare(pb, grad_input && !coh ? CS_STAGE_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (coh) {
         float *acc = nullptr;
@@ -577,7 +595,10 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     Prepared pr;
     // without gInput nothing is scattered: no plan, no fat rows
     const bool coh = !cI && coherent_applies(pb);   // (with grad_out_input: the general path)
-    int rc = prepare(pb, gInput && !coh ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
+    if (pb.sum_n && cI) return CS_ERR_UNSUPPORTED;
+    int rc = sum_n_check(pb, true, false);
+    if (rc) return rc;
+    rc = prepare(pb, gInput && !coh ? CS_STAGE_BACKWARD_BACKWARD : CS_STAGE_FORWARD, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     const float *cIcl = nullptr;
     if (cI) {
@@ -625,7 +646,9 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     Prepared pr;
     const bool coh = coherent_applies(pb);
-    int rc = prepare(pb, coh ? CS_STAGE_FORWARD : CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
+    int rc = sum_n_check(pb, true, hO != nullptr);
+    if (rc) return rc;
+    rc = prepare(pb, coh ? CS_STAGE_FORWARD : CS_STAGE_BBB_FUSED, input, grid, offset, input_cl, plan, ws, pr);
     if (rc) return rc;
     if (coh) {
         float *acc;
@@ -1087,6 +1110,7 @@ template <int DIM>
 int bbb_grid_impl(Problem &pb, const float *input, const float *grid, const float *grad_output,
                          const float *grad_out_grid, const float *grad_out_ggrid, const float *grad_out_ggout,
                          const float *offset, float *grad_grid3) {
+    if (pb.sum_n) return CS_ERR_UNSUPPORTED;
     if (pb.d.S == 0) return CS_OK;
     if (pb.d.C == 0) return zero_async(grad_grid3, pb.d.S * DIM, pb.stream);
     CS_DISPATCH_KERNEL(pb.kernel, (cs::direct_bbb_grid<DIM, KERNEL><<<pb.blocks, kBlock, 0, pb.stream>>>(
@@ -1177,6 +1201,14 @@ int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t 
     return (dim == 3 && rows_cl_applies(3, N, C, P, D * H * W)) ? 1 : 0;
 }
 
+int cs2d_sum_over_n_supported(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners) {
+    if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return 0;
+    if (!tiled_applies(2, N, C, H, W, P)) return 0;
+    Problem pb;
+    if (make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, CS_GRID_BROADCAST | CS_SUM_OVER_N, 1, nullptr)) return 0;
+    return cs::coh::supported_nsum(coh_launch(pb)) ? 1 : 0;
+}
+
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
@@ -1246,6 +1278,7 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
+    if (pb.sum_n && !tiled) return CS_ERR_UNSUPPORTED;                                                            \
     bool g_sorted = false, g_leave = false;                                                                       \
     (void)g_sorted; (void)g_leave;                                                                                \
     const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \

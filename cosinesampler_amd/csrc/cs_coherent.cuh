@@ -334,8 +334,16 @@ struct Args {
 // COMMON: zeros padding with align_corners -- every BASELINE config and the reference's defaults -- as compile-time
 // constants: the padding variants are wave-uniform branches, but they cost scalar registers (the general kernels spill them
 // to vector lanes), scalar instructions and ~40 branches per batch in kernels that are instruction-issue bound.
-template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST, bool COMMON = false>
-__global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
+//
+// NSUM (CS_SUM_OVER_N; SURVEY 8f-1, the PIXEL pattern features = sampler(cells, grid).sum(0), reference test/test_2d.py:38,
+// :51): ONE set of points and ONE set of cotangents serve every table (grid [P,2], gOut / hO [C,P], cG / hG [P,2]) and
+// every per-point result is wanted summed over the tables (output / grad_grad_out [C,P], grad_grid [P,2]); only the
+// input-shaped gradient stays per table.  A wave then owns 128 points for ALL tables: their streams are loaded once and
+// stay in registers, the wave walks the tables one after the other -- table n's window, scatter-reduce into table n's
+// accumulator, products -- adding the per-point results up in registers, and writes them once: the (N,C,P) streams of
+// the plain op, 1 GiB each at BASELINE configs[1], shrink N-fold and the caller's sums over n disappear.
+template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST, bool COMMON = false, bool NSUM = false>
+__global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
     Flags f = f_;
     if constexpr (COMMON) {
         f.pad = PAD_ZEROS;
@@ -353,7 +361,8 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
 #endif
     constexpr int DEPTH = MODE == FWD ? 4 : MODE == BWD ? CS_COH_DEPTH_BWD : 2;         // batches of stream loads in flight per wave
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    int n = NSUM ? 0 : blockIdx.y;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave in block: a scalar
     const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const int64_t p_begin = wv * chunk;
@@ -363,10 +372,10 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
     float *KA = GT + C * L::PT;
     float *TW = ACC ? KA + 64 * KP : GT;
     float *AW = TW + L::WIN;
-    const float off = a.offset[n];
+    float off = a.offset[n];
     const float *tab_n = a.icl + (int64_t)n * d.vol * C;
     float *acc_n = ACC ? a.acc + (int64_t)n * d.vol * C : nullptr;
-    // wave-uniform bases: the first sample of the chunk
+    // wave-uniform bases: the first sample of the chunk (NSUM: n = 0 here, the shared inputs and the summed outputs have no n)
     const float *grid_w = a.grid + (d.gpt(n, p_begin)) * 2;
     const float *cg_w = (MODE >= BB && a.cG) ? a.cG + (d.gpt(n, p_begin)) * 2 : nullptr;
     const float *hg_w = (MODE == BBB && a.hG) ? a.hG + (d.gpt(n, p_begin)) * 2 : nullptr;
@@ -397,7 +406,33 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
         if constexpr (IN) s.sg.issue(go_w, r * (uint32_t)sizeof(ST), d.P, d.C);
         if constexpr (TWO) s.sh.issue(ho_w, r * (uint32_t)sizeof(ST), d.P, d.C);
     };
-    auto batch = [&](Pre &s, int b0) __attribute__((always_inline)) {
+    // per-point results of one batch; NSUM: summed over the tables before they leave
+    struct Res {
+        float O[OUTS ? C : 1];
+        float gx, gy;
+    };
+    auto clear = [&](Res &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < (OUTS ? C : 1); ++c) r.O[c] = 0.0f;
+        r.gx = r.gy = 0.0f;
+    };
+    auto emit = [&](const Res &r, int b0) __attribute__((always_inline)) {
+        const int rel = b0 + lane;
+        const bool live = rel < count;
+        if ((MODE == BWD || MODE == BB) && live)
+            *at(reinterpret_cast<float2 *>(og_w), (uint32_t)rel * 8u) = make_float2(r.gx, r.gy);
+        if (OUTS && live) {
+            int64_t Pv = d.P;
+            asm volatile("" : "+s"(Pv));
+            ST *row = os_w;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (c < d.C) store_out(at(row, (uint32_t)rel * (uint32_t)sizeof(ST)), r.O[c]);
+                row += Pv;
+            }
+        }
+    };
+    auto batch = [&](Pre &s, int b0, Res &res) __attribute__((always_inline)) {
         const int rel = b0 + lane;                            // this lane's sample inside the chunk
         const bool live = rel < count;
         Geo g;
@@ -440,9 +475,8 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
             }
         }
         float Y[4] = {0.f, 0.f, 0.f, 0.f};
-        float O[OUTS ? C : 1];
-#pragma unroll
-        for (int c = 0; c < (OUTS ? C : 1); ++c) O[c] = 0.0f;
+        float(&O)[OUTS ? C : 1] = res.O;
+        if constexpr (!NSUM) clear(res);
 
         // runs of equal quad: heads = first lane of every maximal stretch
         const uint32_t prev = (uint32_t)__shfl_up((int)g.akey, 1);
@@ -512,42 +546,56 @@ __global__ __launch_bounds__(256, CQ > 4 ? 2 : 3) void stage(Args a, Dims d, Fla
             put_coefs(blk, s0, z);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the set is free: its next loads go out, DEPTH batches of work to arrive in
-        if (b0 + 64 * DEPTH < count) issue(s, b0 + 64 * DEPTH);
-        // this batch's outputs leave
+        // the set is free: its next loads go out, DEPTH batches of work to arrive in (NSUM: the sets are loaded once)
+        if constexpr (!NSUM)
+            if (b0 + 64 * DEPTH < count) issue(s, b0 + 64 * DEPTH);
+        // this batch's per-point results
         if (MODE == BWD) {
             const float gx = g.ax[1].w[0] * (Y[1] - Y[0]) + g.ax[1].w[1] * (Y[3] - Y[2]);
             const float gy = g.ax[0].w[0] * (Y[2] - Y[0]) + g.ax[0].w[1] * (Y[3] - Y[1]);
-            if (live) *at(reinterpret_cast<float2 *>(og_w), (uint32_t)rel * 8u) = make_float2(g.ax[0].d1 * gx, g.ax[1].d1 * gy);
+            res.gx = fmaf(g.ax[0].d1, gx, res.gx);
+            res.gy = fmaf(g.ax[1].d1, gy, res.gy);
         }
         if (MODE == BB) {
-            float sx = 0.0f, sy = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                sx = fmaf(Sx[q], Y[q], sx);
-                sy = fmaf(Sy[q], Y[q], sy);
-            }
-            if (live) *at(reinterpret_cast<float2 *>(og_w), (uint32_t)rel * 8u) = make_float2(sx, sy);
-        }
-        if (OUTS && live) {
-            int64_t Pv = d.P;
-            asm volatile("" : "+s"(Pv));
-            ST *row = os_w;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (c < d.C) store_out(at(row, (uint32_t)rel * (uint32_t)sizeof(ST)), O[c]);
-                row += Pv;
+                res.gx = fmaf(Sx[q], Y[q], res.gx);
+                res.gy = fmaf(Sy[q], Y[q], res.gy);
             }
         }
+        if constexpr (!NSUM) emit(res, b0);
     };
     Pre S[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (64 * i < count) issue(S[i], 64 * i);
-    for (int b0 = 0; b0 < count; b0 += 64 * DEPTH) {
+    if constexpr (NSUM) {
+        // chunk = 64 * DEPTH points: both sets stay in registers while the wave walks the tables
+        Res R[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) clear(R[i]);
+        for (int nn = 0; nn < d.N; ++nn) {
+            n = nn;
+            off = a.offset[n];
+            tab_n = a.icl + (int64_t)n * d.vol * C;
+            if (ACC) acc_n = a.acc + (int64_t)n * d.vol * C;
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i)
+                if (64 * i < count) batch(S[i], 64 * i, R[i]);
+            w.flush(acc_n, d);                 // table n's sums leave before the windows move to table n + 1
+            w.tqx = w.aqy = -(1 << 20);
+        }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i)
-            if (b0 + 64 * i < count) batch(S[i], b0 + 64 * i);
+            if (64 * i < count) emit(R[i], 64 * i);
+        return;
+    }
+    for (int b0 = 0; b0 < count; b0 += 64 * DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            Res res;
+            if (b0 + 64 * i < count) batch(S[i], b0 + 64 * i, res);
+        }
     }
     w.flush(acc_n, d);
 }

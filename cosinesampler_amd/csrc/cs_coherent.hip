@@ -58,8 +58,26 @@ Geometry geometry(const Launch &L) {
         default: { using ST = float; COH_KERNEL_((L_).kernel, __VA_ARGS__) } break;                  \
     }
 
+// CS_SUM_OVER_N (cs_coherent.cuh, NSUM): a wave owns 64 * DEPTH points for every table.  Built for fp32 streams with zeros
+// padding and align_corners (the COMMON specialisation): the PIXEL pattern; anything else is the caller's to sum.
+template <int MODE, bool TWO, bool SCAT>
+int launch_nsum(const Launch &L, const Args &a) {
+    const int chunk = 64 * (MODE == FWD ? 4 : 2);          // = 64 * DEPTH of the kernel
+    const int dbg = g_dbg.load(std::memory_order_relaxed);
+    const int64_t waves = (L.d.P + chunk - 1) / chunk;
+    int rc = 0;
+    COH_KERNEL_(L.kernel, COH_CQ(L.cq, {
+        using ST = float;
+        const size_t shm = (size_t)wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
+        rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true, true>, shm);
+        if (!rc) stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true, true><<<dim3((unsigned)waves), 64, shm, L.stream>>>(a, L.d, L.f, chunk, dbg);
+    }));
+    return rc ? rc : status();
+}
+
 template <int MODE, bool TWO, bool SCAT = true>
 int launch(const Launch &L, const Args &a) {
+    if (L.nsum) return launch_nsum<MODE, TWO, SCAT>(L, a);
     const Geometry g = geometry(L);
     int rc = 0;
 #ifndef CS_COH_NO_COMMON
@@ -87,6 +105,12 @@ void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no
     if (samples_per_wave >= 64) g_chunk.store((samples_per_wave + 63) / 64 * 64, std::memory_order_relaxed);
     g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 15) << 3, std::memory_order_relaxed);     // + 256 / 512: store policies (unused now), + 1024: no table-window loads, + 2048: no scatter operands to LDS
     if (((ablation_bits >> 4) & 15) >= 1 && ((ablation_bits >> 4) & 15) <= 4) g_wpb.store((ablation_bits >> 4) & 15, std::memory_order_relaxed);   // waves per workgroup
+}
+
+bool supported_nsum(const Launch &L) {
+    // (the 2D forward ignores align_corners, 2d.cu:307-308: COMMON's align = 1 is what it uses anyway; every other stage
+    // honours the flag, so the caller's must be set)
+    return supported(L) && L.sdt == 0 && L.f.pad == PAD_ZEROS && L.f.align && L.d.grid_ns == 0;
 }
 
 bool supported(const Launch &L) {

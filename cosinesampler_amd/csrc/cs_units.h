@@ -22,8 +22,10 @@ struct Launch {
     Flags f;
     int kernel, sdt, cq;
     hipStream_t stream;
+    bool nsum = false;   // CS_SUM_OVER_N: shared points and cotangents, per-point results summed over the tables (supported_nsum)
 };
 bool supported(const Launch &L);
+bool supported_nsum(const Launch &L);
 int forward(const Launch &L, const float *icl, const float *grid, const float *offset, void *output);
 int backward(const Launch &L, const void *gOut, const float *icl, const float *grid, const float *offset, float *acc,
              float *grad_grid);

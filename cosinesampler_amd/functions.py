@@ -53,13 +53,14 @@ def kernel_enum(kernel):
 
 
 class _Config(object):
-    __slots__ = ("pad", "align_corners", "kernel", "multicell")
+    __slots__ = ("pad", "align_corners", "kernel", "multicell", "sum_n")
 
-    def __init__(self, padding_mode, align_corners, kernel, multicell):
+    def __init__(self, padding_mode, align_corners, kernel, multicell, sum_n=False):
         self.pad = padding_mode_enum(padding_mode)
         self.align_corners = bool(align_corners)
         self.kernel = kernel_enum(kernel)
         self.multicell = bool(multicell)
+        self.sum_n = bool(sum_n)      # CosineSampler{2,3}dSum: one set of points / cotangents, results summed over the tables
 
 
 _offset_cache = {}
@@ -146,10 +147,10 @@ def _through_view(input):
     return input
 
 
-def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multicell):
+def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multicell, sum_n=False):
     if input.dim() != dim + 2:
         raise RuntimeError("CosineSampler%dd expects a %d-D input, got %s" % (dim, dim + 2, tuple(input.shape)))
-    cfg = _Config(padding_mode, align_corners, kernel, multicell)
+    cfg = _Config(padding_mode, align_corners, kernel, multicell, sum_n)
     offset = multicell_offset(input.shape[0], multicell, input.device)
     # channels-last input copy + point plan, shared by this call's backward chain; which grad_output's sorted copy is
     # worth leaving in the plan is decided from the nodes that announce themselves (StepContext.expect)
@@ -157,9 +158,12 @@ def _forward(ctx, dim, input, grid, padding_mode, align_corners, kernel, multice
     x32, g32 = _f32(input), _f32(grid)
     # float16 / bfloat16 callers: the table and the grid (small) are converted, the big channel-major tensors are read and
     # written in the caller's type by the kernels themselves wherever a fast path applies
-    step.half_ok = input.dtype in _HALVES and ops.half_streams_ok(x32, g32)
-    output = _as(ops.forward(x32, g32, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step,
-                             out_dtype=input.dtype if step.half_ok else None), input)
+    step.half_ok = input.dtype in _HALVES and ops.half_streams_ok(x32, g32) and not sum_n
+    if sum_n:
+        output = _as(ops.forward_sum_n(x32, g32, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step), input)
+    else:
+        output = _as(ops.forward(x32, g32, offset, cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step,
+                                 out_dtype=input.dtype if step.half_ok else None), input)
     ctx.save_for_backward(input, grid)
     ctx.offset = offset
     ctx.cfg = cfg
@@ -209,6 +213,48 @@ class CosineSampler3d(Function):
         return _backward(ctx, grad_out)
 
 
+class CosineSampler2dSum(Function):
+    """NOT in the reference: the PIXEL pattern as one op.
+
+        feat = CosineSampler2dSum.apply(cells, points.view(1, 1, P, 2), 'zeros', True, 'cosine', True)      # (1, C, 1, P)
+             = CosineSampler2d.apply(cells, points.view(1, 1, P, 2).repeat(N, 1, 1, 1), ...).sum(0, keepdim=True)
+
+    -- what reference callers write as grid.repeat(N,1,1,1) ... .sum(0) (test/test_2d.py:38, :51) -- differentiable to the same
+    orders.  Every per-point tensor of the chain (output, its cotangents, their gradients) is N times smaller; where the summing
+    kernels apply (2D fast path, fp32, zeros padding with align_corners, points in cell order: ops.sum_over_n_fused) no
+    (N,C,P) tensor is ever materialised, elsewhere the same values come from the plain op and torch sums."""
+
+    @classmethod
+    def apply(cls, input, *args, **kwargs):
+        return super().apply(_through_view(input), *args, **kwargs)
+
+    @staticmethod
+    def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
+        ctx.set_materialize_grads(False)
+        return _forward(ctx, 2, input, grid, padding_mode, align_corners, kernel, multicell, sum_n=True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _backward(ctx, grad_out)
+
+
+class CosineSampler3dSum(Function):
+    """the 3D counterpart of CosineSampler2dSum (plain op + sums: there are no summing kernels in 3D)"""
+
+    @classmethod
+    def apply(cls, input, *args, **kwargs):
+        return super().apply(_through_view(input), *args, **kwargs)
+
+    @staticmethod
+    def forward(ctx, input, grid, padding_mode="zeros", align_corners=True, kernel="cosine", multicell=True):
+        ctx.set_materialize_grads(False)
+        return _forward(ctx, 3, input, grid, padding_mode, align_corners, kernel, multicell, sum_n=True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _backward(ctx, grad_out)
+
+
 class _SamplerBackward(Function):
     """(input, grid, gOut) -> (grad_input, grad_grid); reference CosineSamplerBackward,
     modules_2d.py:47-74."""
@@ -219,9 +265,13 @@ class _SamplerBackward(Function):
         ctx.offset = offset
         ctx.cfg = cfg
         ctx.step = step
-        grad_input, grad_grid = ops.backward(_stream(gOut, step), _f32(input), _f32(grid), offset, cfg.pad,
-                                             cfg.align_corners, bool(input_requires_grad), cfg.kernel, cfg.multicell,
-                                             ctx=step, go_owner=gOut)
+        if cfg.sum_n:
+            grad_input, grad_grid = ops.backward_sum_n(_f32(gOut), _f32(input), _f32(grid), offset, cfg.pad, cfg.align_corners,
+                                                       bool(input_requires_grad), cfg.kernel, cfg.multicell, ctx=step)
+        else:
+            grad_input, grad_grid = ops.backward(_stream(gOut, step), _f32(input), _f32(grid), offset, cfg.pad,
+                                                 cfg.align_corners, bool(input_requires_grad), cfg.kernel, cfg.multicell,
+                                                 ctx=step, go_owner=gOut)
         ctx.save_for_backward(input, grid, gOut)
         return _as(grad_input, input), _as(grad_grid, grid)
 
@@ -249,10 +299,22 @@ class _SamplerBackwardBackward(Function):
         ctx.step = step
         # ('+mixed' with gOutInput runs on kernels without native 16-bit streams: fp32 there)
         go = _f32(gOut) if (cfg.kernel & ops.EXACT_MIXED) and gOutInput is not None else _stream(gOut, step)
-        gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
-                                                     go, offset, cfg.pad, cfg.align_corners,
-                                                     gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step,
-                                                     want_grad_input=bool(want_grad_input), go_owner=gOut)
+        if cfg.sum_n and gOutInput is None:
+            gInput, gGrid, ggOut = ops.backward_backward_sum_n(_f32(gOutGrid), _f32(input), _f32(grid), _f32(gOut), offset,
+                                                               cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=step,
+                                                               want_grad_input=bool(want_grad_input))
+        elif cfg.sum_n:      # a cotangent of grad_input as well (not the PIXEL pattern): the plain op on the expanded gOut
+            N = input.shape[0]
+            gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
+                                                         _f32(gOut).expand((N,) + tuple(gOut.shape[1:])), offset, cfg.pad,
+                                                         cfg.align_corners, True, cfg.kernel, cfg.multicell, ctx=step,
+                                                         want_grad_input=bool(want_grad_input))
+            ggOut = ggOut.sum(0, keepdim=True)
+        else:
+            gInput, gGrid, ggOut = ops.backward_backward(_f32(gOutInput), _f32(gOutGrid), _f32(input), _f32(grid),
+                                                         go, offset, cfg.pad, cfg.align_corners,
+                                                         gOutInput is not None, cfg.kernel, cfg.multicell, ctx=step,
+                                                         want_grad_input=bool(want_grad_input), go_owner=gOut)
         gInput, gGrid, ggOut = _as(gInput, input), _as(gGrid, grid), _as(ggOut, gOut)
         ctx.has_cG = gOutGrid is not None
         if gOutGrid is None:
@@ -277,12 +339,16 @@ class _SamplerBackwardBackward(Function):
         hO = _stream(hO, ctx.step)
         if hO is not None and hO.dtype != gO.dtype:      # mixed types: the streams of one call share one
             gO, hO = _f32(gO), _f32(hO)
-        gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), gO, _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
-                                      cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step, go_owner=gOut)
+        if cfg.sum_n:
+            gInput, ggOut = ops.bbb_fused_sum_n(_f32(input), _f32(grid), _f32(gO), _f32(gOutGrid), hG, _f32(hO), ctx.offset,
+                                                cfg.pad, cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step)
+        else:
+            gInput, ggOut = ops.bbb_fused(_f32(input), _f32(grid), gO, _f32(gOutGrid), hG, hO, ctx.offset, cfg.pad,
+                                          cfg.align_corners, cfg.kernel, cfg.multicell, ctx=ctx.step, go_owner=gOut)
         # '+mixed' kernels also return the gradient w.r.t. grid here (u_xxx, u_xxy): the reference has none
         # (modules_2d.py:111).  Terms through gOutInput are not propagated, as everywhere at this level.
         gGrid3 = None
-        if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and _engine_wants(ctx, 1):
+        if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and not cfg.sum_n and _engine_wants(ctx, 1):
             gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, _f32(hO), ctx.offset, cfg.pad,
                                       cfg.align_corners, cfg.kernel, cfg.multicell), grid)
         return _as(gInput, input), gGrid3, _as(ggOut, gOut), None, None, None, None, None, None

@@ -291,12 +291,12 @@ _force_epoch = 0
 
 
 _force_mode = 0
-_FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST | _lib.POINTS_COHERENT
+_FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST | _lib.POINTS_COHERENT | _lib.SUM_OVER_N
 
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_grad_input=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
-          go_owner=None):
+          go_owner=None, sum_n=False):
     """want_grad_input: the stage produces an input-shaped gradient (it scatters).  go_owner: the caller's tensor that
     `grad_output` was made from (itself unless the autograd layer converted the dtype): what the sorted copy in the plan
     is remembered by."""
@@ -313,8 +313,11 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
         # coherent points (CS_POINTS_COHERENT): the 2D fast path reads the table through on-chip windows and needs no plan
-        coherent = bool(dim == 2 and grid is not None
-                        and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
+        # (sum_n: the summing kernels ARE coherent-points kernels; the caller has decided)
+        coherent = bool(sum_n or (dim == 2 and grid is not None
+                                  and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)))
+        if sum_n:
+            kernel |= _lib.SUM_OVER_N
         if coherent:
             kernel |= _lib.POINTS_COHERENT
         cl = plan = None
@@ -694,6 +697,131 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
           want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner)
+    return grad_input, grad_grad_out
+
+
+
+# ---- the PIXEL pattern as one op: per-point results summed over the tables (CS_SUM_OVER_N) -----------------------------
+# features = sampler(cells, grid.repeat(N,1,1,1)).sum(0) (reference test/test_2d.py:38, :51): one set of points, and -- in
+# every derivative the caller takes -- one cotangent for all N tables and results that are summed over them.  These four
+# functions take and return the n-free tensors ((1,C,..,P) streams, (1,..,P,dim) grid-shaped); input-shaped gradients stay
+# (N,C,H,W).  Where the summing kernels apply (2D fast path, fp32, zeros padding with align_corners, N > 1, C <= 32) and the
+# points are in cell order they run as ONE kernel per stage that never materialises an (N,C,P) stream; anywhere else the
+# same values come from the plain op on expanded inputs followed by torch sums.
+
+
+def sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx=None, kernel=0):
+    """Will the *_sum_n functions run on the summing kernels for this problem (else: plain op + sums)?"""
+    if not (input.is_cuda and grid.is_cuda) or input.dim() != 4 or input.dtype != torch.float32:
+        return False
+    if isinstance(kernel, int) and (kernel & EXACT_MIXED):
+        return False
+    dim, shape, P = _problem(input, grid)
+    if grid.shape[0] != 1 or shape[0] < 2 or _channel_groups(input, dim) or _force_mode == 1:
+        return False
+    lib = _lib.load()
+    if not lib.cs2d_sum_over_n_supported(shape[0], shape[1], shape[2], shape[3], P, int(padding_mode), int(bool(align_corners))):
+        return False
+    with torch.cuda.device(input.device):
+        stream = torch.cuda.current_stream(input.device).cuda_stream
+        return bool(_order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
+
+
+def _one(t, N):
+    return None if t is None else t.expand((N,) + tuple(t.shape[1:]))
+
+
+def _shared(t, like_shape, name, device, stream=False):
+    """an n-free tensor: leading extent 1"""
+    if stream:
+        _check_stream(t, name)
+    else:
+        _check(t, name)
+    _shape_dev(t, (1,) + tuple(like_shape[1:]), name, device)
+
+
+def forward_sum_n(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
+    """-> sum over n of forward(...): (1, C, [Do,] Ho, Wo).  grid: (1, ..., dim)."""
+    input, grid = _al(input, grid)
+    dim, shape, P = _problem(input, grid)
+    if grid.shape[0] != 1:
+        raise RuntimeError("the summed op takes ONE set of points: grid must be (1, ..., %d), got %s" % (dim, tuple(grid.shape)))
+    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel):
+        return forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx).sum(0, keepdim=True)
+    _offset_ok(offset, shape[0], input.device)
+    output = torch.empty((1,) + out_shape(input, grid)[1:], dtype=input.dtype, device=input.device)
+    _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P, padding_mode, align_corners,
+          kernel, multicell, input.device, ctx, input, grid, offset, sum_n=True)
+    return output
+
+
+def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
+                   ctx=None):
+    """grad_output: (1, C, ..., P), the one cotangent of every table -> (grad_input (N,C,H,W) | None, grad_grid (1,...,P,dim))."""
+    grad_output, input, grid = _al(grad_output, input, grid)
+    dim, shape, P = _problem(input, grid)
+    _shared(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or grad_output.dtype != torch.float32:
+        return backward(_one(grad_output, shape[0]), input, grid, offset, padding_mode, align_corners, input_requires_grad,
+                        kernel, multicell, ctx)
+    _offset_ok(offset, shape[0], input.device)
+    grad_input = torch.empty_like(input) if input_requires_grad else None
+    grad_grid = torch.empty_like(grid)
+    _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input), _ptr(grad_grid)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_grad_input=bool(input_requires_grad), go_ns=0, grad_output=grad_output, sum_n=True)
+    return grad_input, grad_grid
+
+
+def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners, kernel, multicell,
+                            ctx=None, want_grad_input=True):
+    """grad_out_input absent.  -> (grad_input (N,C,H,W) | None, grad_grid (1,...,P,dim), grad_grad_out (1,C,...,P))."""
+    grad_out_grid, input, grid, grad_output = _al(grad_out_grid, input, grid, grad_output)
+    dim, shape, P = _problem(input, grid)
+    _shared(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+    if grad_out_grid is not None:
+        _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
+    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or grad_output.dtype != torch.float32:
+        gI, gG, ggO = backward_backward(None, grad_out_grid, input, grid, _one(grad_output, shape[0]), offset, padding_mode,
+                                        align_corners, False, kernel, multicell, ctx, want_grad_input)
+        return gI, gG, ggO.sum(0, keepdim=True)
+    _offset_ok(offset, shape[0], input.device)
+    grad_input = torch.empty_like(input) if want_grad_input else None
+    grad_grid = torch.empty_like(grid)
+    grad_grad_out = torch.empty_like(grad_output)
+    _call("backward_backward", dim,
+          [None, _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset), _ptr(grad_input),
+           _ptr(grad_grid), _ptr(grad_grad_out)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_grad_input=bool(want_grad_input), go_ns=0, grad_output=grad_output, sum_n=True)
+    return grad_input, grad_grid, grad_grad_out
+
+
+def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
+                    align_corners, kernel, multicell, ctx=None):
+    """-> (grad_input (N,C,H,W), grad_grad_out (1,C,...,P)); grad_out_ggout: (1,C,...,P) or None."""
+    input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout = _al(
+        input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout)
+    dim, shape, P = _problem(input, grid)
+    _shared(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
+    if grad_out_ggout is not None:
+        _shared(grad_out_ggout, out_shape(input, grid), "grad_out_ggout", input.device, stream=True)
+    for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
+        if t is not None:
+            _same(t, grid.shape, nm, input.device)
+    fp32 = grad_output.dtype == torch.float32 and (grad_out_ggout is None or grad_out_ggout.dtype == torch.float32)
+    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or not fp32:
+        gI, ggO = bbb_fused(input, grid, _one(grad_output, shape[0]), grad_out_grid, grad_out_ggrid,
+                            _one(grad_out_ggout, shape[0]), offset, padding_mode, align_corners, kernel, multicell, ctx)
+        return gI, ggO.sum(0, keepdim=True)
+    _offset_ok(offset, shape[0], input.device)
+    grad_input = torch.empty_like(input)
+    grad_grad_out = torch.empty_like(grad_output)
+    _call("bbb_fused", dim,
+          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(grad_out_ggout),
+           _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
+          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+          want_grad_input=True, go_ns=0, ho_ns=0, grad_output=grad_output, sum_n=True)
     return grad_input, grad_grad_out
 
 

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 10
+#define CS_ABI_VERSION 11
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -89,6 +89,16 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * has a coherent kernel (forward and the stages without grad_input included); ignored where it does not apply (3D, the
  * second backward with grad_out_input, problems outside the 2D fast path). */
 #define CS_POINTS_COHERENT 0x8000
+/* OR-ed into `kernel`, together with CS_GRID_BROADCAST (not in the reference): the PIXEL pattern
+ * features = sampler(cells, grid.repeat(N,1,1,1)).sum(0) (test/test_2d.py:38, :51) as ONE op.  Every per-point tensor loses
+ * its n: the inputs `grid`, `grad_out_grid`, `grad_out_ggrid` are [P,2] and `grad_output`, `grad_out_ggout` are [C,P] (one
+ * cotangent for every table: pass n-strides 0 in cs_cotangent_layout); the per-point RESULTS come back summed over the
+ * tables -- `output` and `grad_grad_out` [C,P], `grad_grid` [P,2].  Input-shaped gradients stay [N,C,H,W].  Equal to the plain
+ * op on repeated / expanded inputs followed by sums over n, without the N-fold streams in between.  Runs on the
+ * coherent-points kernels (fast for points in cell order, correct for any); built for 2D, fp32 streams, zeros padding with
+ * align_corners (cs2d_sum_over_n_supported), CS_ERR_UNSUPPORTED otherwise -- the caller then sums himself.  Workspace as
+ * for CS_STAGE_POINTS_COHERENT. */
+#define CS_SUM_OVER_N 0x10000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
 /* OR-ed into the stage id: the call will pass grad_input == NULL (first / second backward only) -- nothing is
@@ -131,6 +141,7 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
                           int have_input_cl, int have_plan, int have_cI);
 
 /* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
+int cs2d_sum_over_n_supported(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners);
 int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 
 /* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C padded with zero channels to 4, 8, 16 or 32

@@ -59,10 +59,41 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
                                offset, padding_mode, align_corners, kernel, multicell)
 
 
+# the summed op (ops.*_sum_n, CosineSampler{2,3}dSum): n-free cotangents expanded, per-point results summed -- the reference's
+# own way of writing the PIXEL pattern
+def _x(t, input):
+    return None if t is None else t.expand((input.shape[0],) + tuple(t.shape[1:]))
+
+
+def forward_sum_n(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None):
+    return forward(input, grid, offset, padding_mode, align_corners, kernel, multicell).sum(0, keepdim=True)
+
+
+def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
+                   ctx=None):
+    return backward(_x(grad_output, input), input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel,
+                    multicell)
+
+
+def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners, kernel, multicell,
+                            ctx=None, want_grad_input=True):
+    gi, gg, ggo = backward_backward(None, grad_out_grid, input, grid, _x(grad_output, input), offset, padding_mode,
+                                    align_corners, False, kernel, multicell, want_grad_input=want_grad_input)
+    return gi, gg, ggo.sum(0, keepdim=True)
+
+
+def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
+                    align_corners, kernel, multicell, ctx=None):
+    gi, ggo = bbb_fused(input, grid, _x(grad_output, input), grad_out_grid, grad_out_ggrid, _x(grad_out_ggout, input), offset,
+                        padding_mode, align_corners, kernel, multicell)
+    return gi, ggo.sum(0, keepdim=True)
+
+
 SKIPPED = []   # per backward_backward call: was grad_input declared unwanted?
 
 
 def install(monkeypatch):
     from cosinesampler_amd import ops
-    for name in ("forward", "backward", "backward_backward", "bbb_fused"):
+    for name in ("forward", "backward", "backward_backward", "bbb_fused", "forward_sum_n", "backward_sum_n",
+                 "backward_backward_sum_n", "bbb_fused_sum_n"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -517,7 +517,7 @@ def test_full_size_helmholtz_autograd(order):
     chosen by the op's own measurement).  Checked: (a) a (1,1,P,2) broadcast grid gives what the repeated grid gives;
     (b) on a 4096-point slice, u, u_x, u_xx and d(loss restricted to the slice)/d cells against the exact-derivative
     composite (oracle/composite.py, float64 on the GPU: the checker, not the product) evaluated on the slice alone."""
-    from cosinesampler_amd import CosineSampler2d
+    from cosinesampler_amd import CosineSampler2d, CosineSampler2dSum
     from oracle import composite
     N, C, H, P, K = 16, 16, 256, 1 << 20, 4096
     g = torch.Generator().manual_seed(31)
@@ -533,16 +533,19 @@ def test_full_size_helmholtz_autograd(order):
     mask = torch.zeros(P, 1, device=DEV)
     mask[sel] = 1.0
 
-    def step(bc):
+    def step(bc, summed=False):
         cells = cells0.clone().requires_grad_(True)
         x = xy[:, :1].clone().requires_grad_(True)
         y = xy[:, 1:].clone().requires_grad_(True)
         ones = torch.ones(P, 1, device=DEV)
         grid = torch.cat([x, y], -1).view(1, 1, P, 2)
-        if not bc:
-            grid = grid.repeat(N, 1, 1, 1)
-        val = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True)
-        u = torch.tanh(val.sum(0).view(C, -1).t() @ W1.t()) @ W2.t()
+        if summed:          # (c) sampler(...).sum(0) as one op: on ordered points the summing kernels, else plain op + sums
+            feat = CosineSampler2dSum.apply(cells, grid, "zeros", True, "cosine", True)[0]
+        else:
+            if not bc:
+                grid = grid.repeat(N, 1, 1, 1)
+            feat = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True).sum(0)
+        u = torch.tanh(feat.view(C, -1).t() @ W1.t()) @ W2.t()
         u_x, u_y = torch.autograd.grad(u, (x, y), ones, create_graph=True)
         (u_xx,) = torch.autograd.grad(u_x, x, ones, create_graph=True)
         (u_yy,) = torch.autograd.grad(u_y, y, ones, create_graph=True)
@@ -557,11 +560,14 @@ def test_full_size_helmholtz_autograd(order):
         torch.cuda.synchronize()
     rep = step(False)
     bcr = step(True)
+    smd = step(True, summed=True)
     torch.cuda.synchronize()
     if order == "sorted":
         assert any(st[0] for st in ops._order_state.values()), "ordered points were not recognised"
+        assert ops.sum_over_n_fused(cells0, xy.view(1, 1, P, 2), 0, True, True), "the summing kernels were not used"
     for k in rep:
         assert rel_err(bcr[k], rep[k]) <= 2e-5, "broadcast vs repeated grid: %s %.2e" % (k, rel_err(bcr[k], rep[k]))
+        assert rel_err(smd[k], rep[k]) <= 2e-5, "summed op vs repeat + sum: %s %.2e" % (k, rel_err(smd[k], rep[k]))
     # the slice against the composite in float64
     cells = cells0.double().clone().requires_grad_(True)
     x = xy[sel, :1].double().clone().requires_grad_(True)
@@ -620,3 +626,121 @@ def test_plan_cache_reuses_the_plan_of_an_unchanged_grid():
     finally:
         ops.plan_cache(0)
         ops.force_path(0)
+
+
+# ---- CS_SUM_OVER_N: the PIXEL pattern (one set of points and cotangents, per-point results summed over the tables) -------
+def _sum_n_case(N, C, size, P, seed, order="sorted"):
+    pts = _order(_points(P, 2, seed=seed), size, order, 0, True, True, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 7)
+    return dict(inp=torch.rand((N, C) + tuple(size), generator=g), grid=pts.view(1, 1, P, 2).contiguous(),
+                gOut=torch.randn(1, C, 1, P, generator=g), cG=torch.randn(1, 1, P, 2, generator=g),
+                hG=torch.randn(1, 1, P, 2, generator=g), hO=torch.randn(1, C, 1, P, generator=g))
+
+
+def _sum_n_oracle(t, off, ke, mc):
+    """the reference's way: repeated grid, expanded cotangents, sums over n afterwards (test/test_2d.py:38, :51)"""
+    N = t["inp"].shape[0]
+    rep = lambda x: x.repeat((N,) + (1,) * (x.dim() - 1)).contiguous()
+    grid, gOut, cG, hG, hO = (rep(t[k]) for k in ("grid", "gOut", "cG", "hG", "hO"))
+    s0 = lambda x: x.sum(0, keepdim=True)
+    r = {}
+    r["out"] = s0(cs_oracle.forward(t["inp"], grid, off, 0, True, ke, mc))
+    gI, gG = cs_oracle.backward(gOut, t["inp"], grid, off, 0, True, True, ke, mc)
+    r["gI"], r["gG"] = gI, s0(gG)
+    bI, bG, bO = cs_oracle.backward_backward(None, cG, t["inp"], grid, gOut, off, 0, True, False, ke, mc)
+    r["bbI"], r["bbG"], r["bbO"] = bI, s0(bG), s0(bO)
+    fI, fO = cs_oracle.bbb_fused(t["inp"], grid, gOut, cG, hG, hO, off, 0, True, ke, mc)
+    r["fI"], r["fO"] = fI, s0(fO)
+    kI, kO = cs_oracle.backward_backward_backward(t["inp"], grid, gOut, cG, hG, off, 0, True, True, ke, mc)   # no gOutggOut
+    r["kI"], r["kO"] = kI, s0(kO)
+    return r
+
+
+def _sum_n_gpu(t, off, ke, mc, ctx):
+    x = {k: v.to(DEV) for k, v in t.items()}
+    o = off.to(DEV)
+    r = {}
+    r["out"] = ops.forward_sum_n(x["inp"], x["grid"], o, 0, True, ke, mc, ctx=ctx)
+    r["gI"], r["gG"] = ops.backward_sum_n(x["gOut"], x["inp"], x["grid"], o, 0, True, True, ke, mc, ctx=ctx)
+    none_gi, gG0 = ops.backward_sum_n(x["gOut"], x["inp"], x["grid"], o, 0, True, False, ke, mc, ctx=ctx)
+    assert none_gi is None and rel_err(gG0, r["gG"]) <= 1e-6
+    r["bbI"], r["bbG"], r["bbO"] = ops.backward_backward_sum_n(x["cG"], x["inp"], x["grid"], x["gOut"], o, 0, True, ke, mc, ctx=ctx)
+    n2, bG0, bO0 = ops.backward_backward_sum_n(x["cG"], x["inp"], x["grid"], x["gOut"], o, 0, True, ke, mc, ctx=ctx,
+                                               want_grad_input=False)
+    assert n2 is None and rel_err(bG0, r["bbG"]) <= 1e-6 and rel_err(bO0, r["bbO"]) <= 1e-6
+    r["fI"], r["fO"] = ops.bbb_fused_sum_n(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], o, 0, True, ke, mc, ctx=ctx)
+    r["kI"], r["kO"] = ops.bbb_fused_sum_n(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], None, o, 0, True, ke, mc, ctx=ctx)
+    torch.cuda.synchronize()
+    return r
+
+
+@pytest.mark.parametrize("N,C,size,P", [(4, 16, (64, 64), 40000), (3, 8, (37, 50), 20011), (16, 4, (32, 32), 30000),
+                                        (2, 32, (40, 40), 9000), (5, 3, (20, 33), 5000), (4, 12, (48, 48), 12345),
+                                        (3, 16, (16, 16), 3), (2, 8, (16, 16), 63), (2, 8, (16, 16), 129), (6, 16, (24, 24), 257)])
+@pytest.mark.parametrize("ke,mc", [(0, True), (2, True), (1, False)])
+@pytest.mark.parametrize("order", ["sorted", "random"])
+def test_sum_over_n_kernels_match_the_cpu_oracle(N, C, size, P, ke, mc, order):
+    """the summing kernels (forced on: ops.points_order('coherent'); they are correct for any order) against the oracle run
+    the reference's way -- repeated grid, expanded cotangents, sums over n afterwards"""
+    if order == "random" and P > 20000:
+        pytest.skip("unordered points on the coherent kernels: correct but slow; the smaller cases cover it")
+    t = _sum_n_case(N, C, size, P, seed=100 + C + P % 97, order=order)
+    off = offsets(N, mc)
+    want = _sum_n_oracle(t, off, ke, mc)
+    ops.points_order("coherent")
+    ops.force_path(2)
+    try:
+        assert ops.sum_over_n_fused(t["inp"].to(DEV), t["grid"].to(DEV), 0, True, mc), "the summing kernels do not apply"
+        got = _sum_n_gpu(t, off, ke, mc, ops.StepContext())
+        got_noctx = _sum_n_gpu(t, off, ke, mc, None)
+    finally:
+        ops.force_path(0)
+        ops.points_order("auto")
+    for k in want:
+        assert_close(got[k], want[k], "sum over n (%s points) %s" % (order, k))
+        assert_close(got_noctx[k], want[k], "sum over n, no context (%s points) %s" % (order, k))
+
+
+@pytest.mark.parametrize("why", ["unordered", "border", "align_false", "3d", "one_table", "bf16"])
+def test_sum_over_n_falls_back_to_the_plain_op_and_sums(why):
+    """where the summing kernels do not apply the *_sum_n functions give the same values from the plain op + torch sums"""
+    N, C, size, P, pad, align, ke, mc = 4, 8, (32, 32), 20000, 0, True, 0, True
+    t = _sum_n_case(N, C, size, P, seed=9)
+    if why == "one_table":
+        t["inp"] = t["inp"][:1].contiguous()
+        N = 1
+    off = offsets(N, mc)
+    x = {k: v.to(DEV) for k, v in t.items()}
+    o = off.to(DEV)
+    ops.points_order("random" if why == "unordered" else "coherent")
+    ops.force_path(2)
+    try:
+        if why == "border":
+            pad = 1
+        if why == "align_false":
+            align = False
+        if why == "3d":
+            g = torch.Generator().manual_seed(3)
+            x = dict(inp=torch.rand(3, 4, 8, 9, 10, generator=g).to(DEV), grid=(torch.rand(1, 1, 1, 3000, 3, generator=g) * 2 - 1).to(DEV),
+                     gOut=torch.randn(1, 4, 1, 1, 3000, generator=g).to(DEV))
+            o = offsets(3, mc).to(DEV)
+            N = 3
+        if why == "bf16":
+            x["gOut"] = x["gOut"].bfloat16()
+        assert not ops.sum_over_n_fused(x["inp"], x["grid"], pad, align, mc) or why == "bf16"
+        out = ops.forward_sum_n(x["inp"], x["grid"], o, pad, align, ke, mc)
+        gI, gG = ops.backward_sum_n(x["gOut"], x["inp"], x["grid"], o, pad, align, True, ke, mc)
+        rep = x["grid"].repeat((N,) + (1,) * (x["grid"].dim() - 1)).contiguous() if N > 1 else x["grid"]
+        ops.points_order("random")
+        out_p = ops.forward(x["inp"], rep, o, pad, align, ke, mc).sum(0, keepdim=True)
+        gI_p, gG_p = ops.backward(x["gOut"].expand((N,) + tuple(x["gOut"].shape[1:])).contiguous(), x["inp"], rep, o, pad, align,
+                                  True, ke, mc)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+        ops.points_order("auto")
+    tol = 1e-2 if why == "bf16" else 1e-5
+    assert out.shape[0] == 1 and gG.shape[0] == 1 and gI.shape == x["inp"].shape
+    assert_close(out, out_p, "fallback forward (%s)" % why, tol=1e-5)
+    assert_close(gI.float(), gI_p.float(), "fallback grad_input (%s)" % why, tol=tol)
+    assert_close(gG.float(), gG_p.sum(0, keepdim=True).float(), "fallback grad_grid (%s)" % why, tol=tol)

@@ -304,3 +304,35 @@ def test_grad_reducer_sums_locally_without_a_process_group():
         assert torch.equal(GradReducer(schedule=schedule).finish(out=torch.ones(2)), torch.zeros(2))
     with pytest.raises(ValueError):
         GradReducer(schedule="sometimes")
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_summed_op_equals_the_repeat_sum_pattern_through_autograd(monkeypatch, d):
+    """CosineSampler{2,3}dSum.apply(cells, points) = CosineSampler{2,3}d.apply(cells, points.repeat(N, ...)).sum(0, keepdim=True)
+    (reference test/test_2d.py:38, :51 as one op), and so are its first, second and third derivatives -- the Function chain
+    with the oracle as the backend; the kernels behind it are compared with the oracle on the GPU (tests/test_coherent_gpu.py)."""
+    oracle_backend.install(monkeypatch)
+    from cosinesampler_amd import CosineSampler2dSum, CosineSampler3d, CosineSampler3dSum
+    Plain, Summed = (CosineSampler2d, CosineSampler2dSum) if d == 2 else (CosineSampler3d, CosineSampler3dSum)
+    torch.manual_seed(11 + d)
+    N, C, P = 3, 2, 40
+    cells0 = torch.rand((N, C) + (6,) * d)
+    pts0 = torch.rand((1,) + (1,) * (d - 1) + (P, d)) * 1.8 - 0.9
+    W = torch.rand(C, 1)
+    res = []
+    for summed in (True, False):
+        cells = cells0.clone().requires_grad_(True)
+        pts = pts0.clone().requires_grad_(True)
+        if summed:
+            feat = Summed.apply(cells, pts, "zeros", True, "cosine", True)
+            assert feat.shape == (1, C) + (1,) * (d - 1) + (P,)
+        else:
+            feat = Plain.apply(cells, pts.repeat((N,) + (1,) * (d + 1)), "zeros", True, "cosine", True).sum(0, keepdim=True)
+        u = torch.tanh(feat.reshape(C, P).t() @ W)
+        (u_g,) = torch.autograd.grad(u.sum(), pts, create_graph=True)
+        (u_gg,) = torch.autograd.grad(u_g[..., 0].sum(), pts, create_graph=True)
+        loss = ((u_gg[..., 0] + u_gg[..., 1]) ** 2).mean() + (u ** 2).mean()
+        (gc,) = torch.autograd.grad(loss, cells)
+        res.append((feat.detach(), u_g.detach(), u_gg.detach(), gc))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
