@@ -11,7 +11,7 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 ours=[r for r in rows if "cs::" in r["Name"] or "zero_fill" in r["Name"] or "_ZN2cs" in r["Name"]]
 other=[r for r in rows if r not in ours]
-steps=6.0 if __import__('os').environ.get('HELM') == 'sorted' else 4.0   # (ordered points: 3 warm-up steps)
+steps=6.0 if __import__('os').environ.get('HELM') in ('sorted', 'summed') else 4.0   # (ordered points: 3 warm-up steps)
 t=lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)/1e6/steps
 print("sampler kernels %.2f ms/step, torch glue %.2f ms/step" % (t(ours), t(other)))
 for r in sorted(rows, key=lambda r:-float(r["TotalDurationNs"]))[:40]:
