@@ -674,16 +674,19 @@ def _sum_n_gpu(t, off, ke, mc, ctx):
     return r
 
 
-@pytest.mark.parametrize("N,C,size,P", [(4, 16, (64, 64), 40000), (3, 8, (37, 50), 20011), (16, 4, (32, 32), 30000),
-                                        (2, 32, (40, 40), 9000), (5, 3, (20, 33), 5000), (4, 12, (48, 48), 12345),
-                                        (3, 16, (16, 16), 3), (2, 8, (16, 16), 63), (2, 8, (16, 16), 129), (6, 16, (24, 24), 257)])
+_SUM_N_SHAPES = [(4, 16, (64, 64), 40000), (3, 8, (37, 50), 20011), (16, 4, (32, 32), 30000), (2, 32, (40, 40), 9000),
+                 (5, 3, (20, 33), 5000), (4, 12, (48, 48), 12345), (3, 16, (16, 16), 3), (2, 8, (16, 16), 63),
+                 (2, 8, (16, 16), 129), (6, 16, (24, 24), 257)]
+# (unordered points on the coherent kernels are correct but slow -- a window reload per sample: the smaller shapes cover them)
+_SUM_N_CASES = [(sh, "sorted") for sh in _SUM_N_SHAPES] + [(sh, "random") for sh in _SUM_N_SHAPES if sh[3] <= 5000]
+
+
+@pytest.mark.parametrize("shape,order", _SUM_N_CASES)
 @pytest.mark.parametrize("ke,mc", [(0, True), (2, True), (1, False)])
-@pytest.mark.parametrize("order", ["sorted", "random"])
-def test_sum_over_n_kernels_match_the_cpu_oracle(N, C, size, P, ke, mc, order):
+def test_sum_over_n_kernels_match_the_cpu_oracle(shape, order, ke, mc):
     """the summing kernels (forced on: ops.points_order('coherent'); they are correct for any order) against the oracle run
     the reference's way -- repeated grid, expanded cotangents, sums over n afterwards"""
-    if order == "random" and P > 20000:
-        pytest.skip("unordered points on the coherent kernels: correct but slow; the smaller cases cover it")
+    N, C, size, P = shape
     t = _sum_n_case(N, C, size, P, seed=100 + C + P % 97, order=order)
     off = offsets(N, mc)
     want = _sum_n_oracle(t, off, ke, mc)

@@ -77,10 +77,10 @@ stages = {
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
     # the headline step on ORDERED points (bench.py presorted_points): coherent kernels, no plan; each scatter stage also
     # clears a channels-last accumulator (zero_fill, T bytes written) and unpacks it (cs::unpack_cl4)
-    "ordered_forward": ["cs::pack_cl4$", "cs::coh::stage<0, 4, 0, false, true, float"],
-    "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float", "cs::unpack_cl4"],
-    "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float", "cs::unpack_cl4"],
-    "ordered_bbb_fused": ["cs::coh::stage<0, 4, 3, true, true, float", "cs::unpack_cl4"],
+    "ordered_forward": ["cs::pack_cl4$", "cs::coh::stage<0, 4, 0, false, true, float, true, false>$"],
+    "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float, true, false>$", "cs::unpack_cl4"],
+    "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float, true, false>$", "cs::unpack_cl4"],
+    "ordered_bbb_fused": ["cs::coh::stage<0, 4, 3, true, true, float, true, false>$", "cs::unpack_cl4"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
     "3d_forward": ["cs::pack_cl4_zcol", "cs::cl::forward<3, 2, 2, float>"],
     "3d_plan": ["cs::tiles3::plan_count3t", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiles3::plan_scatter3t"],
