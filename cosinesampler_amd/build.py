@@ -18,14 +18,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libcosine_sampler_hip.so")
-SOURCES = ["cs_abi.hip", "cs_coherent.hip", "cs_sort.hip"]
+SOURCES = ["cs_abi.hip", "cs_coherent.hip", "cs_coherent_sum.hip", "cs_sort.hip"]
 ARCH = "gfx950"
 # cs_coherent without the SLP vectoriser: it packs the per-sample fma chains into v_pk_fma_f32 and keeps a splatted copy
 # of every multiplier alive for them (coherent forward: 92 -> 168 registers per lane and spills; MI355X_MICROARCH.md
 # "packed f32 VALU").  The tiled / 3D kernels of cs_abi keep it: A/B on one box, headline step 5.43 ms with, 5.52 without
 # (profiles/round3_ablation.txt).
 COMMON_FLAGS = []
-EXTRA_FLAGS = {"cs_coherent.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"cs_coherent.hip": ["-fno-slp-vectorize"], "cs_coherent_sum.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps():

@@ -9,6 +9,8 @@
 
 namespace cs {
 namespace coh {
+// the summing kernels (CS_SUM_OVER_N) are compiled in their own unit, cs_coherent_sum.hip
+int launch_nsum(int mode, bool two, bool scat, const Launch &L, const Args &a, int dbg);
 namespace {
 
 std::atomic<int> g_dbg{0}, g_chunk{512}, g_wpb{1};
@@ -58,26 +60,9 @@ Geometry geometry(const Launch &L) {
         default: { using ST = float; COH_KERNEL_((L_).kernel, __VA_ARGS__) } break;                  \
     }
 
-// CS_SUM_OVER_N (cs_coherent.cuh, NSUM): a wave owns 64 * DEPTH points for every table.  Built for fp32 streams with zeros
-// padding and align_corners (the COMMON specialisation): the PIXEL pattern; anything else is the caller's to sum.
-template <int MODE, bool TWO, bool SCAT>
-int launch_nsum(const Launch &L, const Args &a) {
-    const int chunk = 64 * (MODE == FWD ? 4 : 2);          // = 64 * DEPTH of the kernel
-    const int dbg = g_dbg.load(std::memory_order_relaxed);
-    const int64_t waves = (L.d.P + chunk - 1) / chunk;
-    int rc = 0;
-    COH_KERNEL_(L.kernel, COH_CQ(L.cq, {
-        using ST = float;
-        const size_t shm = (size_t)wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
-        rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true, true>, shm);
-        if (!rc) stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true, true><<<dim3((unsigned)waves), 64, shm, L.stream>>>(a, L.d, L.f, chunk, dbg);
-    }));
-    return rc ? rc : status();
-}
-
 template <int MODE, bool TWO, bool SCAT = true>
 int launch(const Launch &L, const Args &a) {
-    if (L.nsum) return launch_nsum<MODE, TWO, SCAT>(L, a);
+    if (L.nsum) return launch_nsum(MODE, TWO, SCAT, L, a, g_dbg.load(std::memory_order_relaxed));   // cs_coherent_sum.hip
     const Geometry g = geometry(L);
     int rc = 0;
 #ifndef CS_COH_NO_COMMON

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS--fno-slp-vectorize} $3 \
       -o $R/cosinesampler_amd/lib/obj/alt_$2_$U.o $R/cosinesampler_amd/csrc/$U.hip
   OBJS=""
-  for u in cs_abi cs_coherent cs_sort; do
+  for u in cs_abi cs_coherent cs_coherent_sum cs_sort; do
     if [ $u = $U ]; then OBJS="$OBJS $R/cosinesampler_amd/lib/obj/alt_$2_$U.o"; else OBJS="$OBJS $R/cosinesampler_amd/lib/obj/$u.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$R/cosinesampler_amd/csrc/exports.map \
