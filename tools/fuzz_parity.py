@@ -68,6 +68,38 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
     return r
 
 
+def run_sum_n(mod, t, off, pad, align, ke, mc, dev, shared):
+    """the summed op (ops.*_sum_n; CS_SUM_OVER_N where it applies, else the plain op + sums): one set of points and ONE
+    cotangent for every table, per-point results summed over the tables.  Oracle: the reference's way -- repeat, expand, sum."""
+    x = {k: v.to(dev) for k, v in t.items()}
+    N = x["inp"].shape[0]
+    one = {k: x[k][:1].contiguous() for k in ("grid", "cG", "hG", "gOut", "hO")}
+    off = off.to(dev)
+    r = {}
+    if mod is cs_oracle:
+        rep = {k: v.repeat((N,) + (1,) * (v.dim() - 1)).contiguous() for k, v in one.items()}
+        s0 = lambda a: a.sum(0, keepdim=True)
+        r["s_out"] = s0(mod.forward(x["inp"], rep["grid"], off, pad, align, ke, mc))
+        gI, gG = mod.backward(rep["gOut"], x["inp"], rep["grid"], off, pad, align, True, ke, mc)
+        r["s_gI"], r["s_gG"] = gI, s0(gG)
+        bI, bG, bO = mod.backward_backward(None, rep["cG"], x["inp"], rep["grid"], rep["gOut"], off, pad, align, False, ke, mc)
+        r["s_bbI"], r["s_bbG"], r["s_bbO"] = bI, s0(bG), s0(bO)
+        fI, fO = mod.bbb_fused(x["inp"], rep["grid"], rep["gOut"], rep["cG"], rep["hG"], rep["hO"], off, pad, align, ke, mc)
+        r["s_fI"], r["s_fO"] = fI, s0(fO)
+        for k, v in (("s_gG", gG), ("s_bbG", bG), ("s_bbO", bO), ("s_fO", fO), ("s_out", None)):
+            if v is not None:
+                SCALE[k] = float(v.abs().max())
+        return r
+    kw = {"ctx": ops.StepContext()} if shared else {}
+    r["s_out"] = ops.forward_sum_n(x["inp"], one["grid"], off, pad, align, ke, mc, **kw)
+    r["s_gI"], r["s_gG"] = ops.backward_sum_n(one["gOut"], x["inp"], one["grid"], off, pad, align, True, ke, mc, **kw)
+    r["s_bbI"], r["s_bbG"], r["s_bbO"] = ops.backward_backward_sum_n(one["cG"], x["inp"], one["grid"], one["gOut"], off, pad,
+                                                                    align, ke, mc, **kw)
+    r["s_fI"], r["s_fO"] = ops.bbb_fused_sum_n(x["inp"], one["grid"], one["gOut"], one["cG"], one["hG"], one["hO"], off, pad,
+                                               align, ke, mc, **kw)
+    return r
+
+
 bad = 0
 for case in range(cases):
     d = rng.choice([2, 2, 3])
@@ -108,10 +140,14 @@ for case in range(cases):
     off = multicell_offset(N, mc, "cpu")
     SCALE.clear()
     want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc)
+    if bc:
+        want.update(run_sum_n(cs_oracle, t, off, pad, align, ke, mc, "cpu", False))
     ops.force_path(force)
     ops.points_order(hint)
     try:
         got = run(ops, t, off, pad, align, ke, mc, DEV, shared, bc)
+        if bc:
+            got.update(run_sum_n(ops, t, off, pad, align, ke, mc, DEV, shared))
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)
