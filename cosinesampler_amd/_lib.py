@@ -15,7 +15,8 @@ _c_sz = ctypes.c_size_t
 class CotangentLayout(ctypes.Structure):
     """cs_cotangent_layout (include/cosine_sampler.h): n-strides, in elements, of grad_output / grad_out_ggout."""
     _fields_ = [("grad_output_stride_n", ctypes.c_int64), ("grad_out_ggout_stride_n", ctypes.c_int64),
-                ("sorted_grad_output_valid", ctypes.c_int32), ("leave_sorted_grad_output", ctypes.c_int32)]
+                ("sorted_grad_output_valid", ctypes.c_int32), ("leave_sorted_grad_output", ctypes.c_int32),
+                ("grad_grad_out_stride_n", ctypes.c_int64)]
 
 
 # name -> number of leading pointer args; then (N, C, [D], H, W, P), 4 int flags, [layout*, backward stages only],
@@ -33,7 +34,7 @@ EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_
             "cs_points_tile_changes", "cs_points_tile_changes_sampled", "cs_debug_coherent_tuning", "cs2d_sum_over_n_supported"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
 GRID_BROADCAST = 0x4000                   # CS_GRID_BROADCAST, OR-ed into `kernel` / the plan builders' `flags`

@@ -62,7 +62,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.d.vol = D * H * W;
     pb.d.tab_ns = 1;          // gathers read the caller's NC[D]HW tensor unless a stage switches to a channels-last copy
     pb.d.tab_cs = pb.d.vol;
-    pb.d.go_ns = pb.d.ho_ns = C * P;   // contiguous cotangents unless the entry point is given a layout
+    pb.d.go_ns = pb.d.ho_ns = pb.d.out_ns = C * P;   // contiguous streams unless the entry point is given a layout
     pb.d.grid_ns = grid_bc ? 0 : P;
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
@@ -1121,7 +1121,7 @@ int bbb_grid_impl(Problem &pb, const float *input, const float *grid, const floa
 
 // 16-bit streams move as dwords shared by lane pairs (cs_tiled.cuh ld_pair16) when every channel row starts on a dword
 void pair_streams(Problem &pb, std::initializer_list<const void *> streams) {
-    bool ok = pb.sdt != 0 && pb.d.P % 2 == 0 && pb.d.go_ns % 2 == 0 && pb.d.ho_ns % 2 == 0;
+    bool ok = pb.sdt != 0 && pb.d.P % 2 == 0 && pb.d.go_ns % 2 == 0 && pb.d.ho_ns % 2 == 0 && pb.d.out_ns % 2 == 0;
     for (const void *q : streams) ok = ok && (reinterpret_cast<uintptr_t>(q) & 3) == 0;
     pb.f.pair16 = ok ? 1 : 0;
 }
@@ -1294,6 +1294,10 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (layout->grad_output_stride_n < 0 || layout->grad_out_ggout_stride_n < 0) return CS_ERR_INVALID; \
         pb.d.go_ns = layout->grad_output_stride_n;                                                   \
         pb.d.ho_ns = layout->grad_out_ggout_stride_n;                                                \
+        if (layout->grad_grad_out_stride_n) {                                                        \
+            if (layout->grad_grad_out_stride_n < C * P) return CS_ERR_INVALID;                       \
+            pb.d.out_ns = layout->grad_grad_out_stride_n;                                            \
+        }                                                                                            \
         g_sorted = layout->sorted_grad_output_valid != 0;                                            \
         g_leave = layout->leave_sorted_grad_output != 0;                                             \
     }

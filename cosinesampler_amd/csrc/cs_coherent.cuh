@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
     const float *hg_w = (MODE == BBB && a.hG) ? a.hG + (d.gpt(n, p_begin)) * 2 : nullptr;
     const ST *go_w = IN ? (const ST *)a.gOut + (int64_t)n * d.go_ns + p_begin : nullptr;
     const ST *ho_w = TWO ? (const ST *)a.hO + (int64_t)n * d.ho_ns + p_begin : nullptr;
-    ST *os_w = OUTS ? (ST *)a.out_stream + (int64_t)n * d.C * d.P + p_begin : nullptr;
+    ST *os_w = OUTS ? (ST *)a.out_stream + (int64_t)n * d.out_ns + p_begin : nullptr;
     float *og_w = (MODE == BWD || MODE == BB) ? a.out_grid + ((int64_t)n * d.P + p_begin) * 2 : nullptr;
 
     Windows<C, ACC> w;

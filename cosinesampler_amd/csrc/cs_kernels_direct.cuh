@@ -30,6 +30,8 @@ struct Dims {
     // channels-last copy made by pack_channels_last (one node = one contiguous C-float row)
     int64_t tab_ns, tab_cs;
     int64_t go_ns, ho_ns;   // elements between consecutive n of gOut / hO: C*P, or 0 for an n-broadcast (expanded) tensor
+    int64_t out_ns;         // ... of the stream a stage WRITES (output, grad_grad_out): C*P, or more when the caller's tensor has
+                            // more channels than this call computes (a channel range of a wider stream: cs_cotangent_layout)
     // points between consecutive n of grid, grad_out_grid and grad_out_ggrid: P, or 0 when ONE set of P points serves
     // every n (CS_GRID_BROADCAST: PIXEL's grid.repeat(N, ...), test/test_2d.py:38, without the repeat)
     int64_t grid_ns;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void direct_forward(const float *__restrict__ 
     float W[NC];
     sm.weights(W);
     const float *in = input + (int64_t)sm.n * d.C * d.vol;
-    float *o = out + (int64_t)sm.n * d.C * d.P + sm.p;
+    float *o = out + (int64_t)sm.n * d.out_ns + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float v[NC];
         gather<DIM>(in, sm.node, v, d.tab_ns);
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void direct_backward_backward(
     const float *ci = cI ? cI + (int64_t)sm.n * d.C * d.vol : nullptr;
     float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
     const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    float *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
         float v[NC];
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void direct_bbb_fused(
     float *gi = gInput ? gInput + (int64_t)sm.n * d.C * d.vol : nullptr;
     const float *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
     const float *ho = hO ? hO + (int64_t)sm.n * d.ho_ns + sm.p : nullptr;
-    float *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    float *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
     for (int c = 0; c < d.C; ++c) {
         float g = *go;
         float h = ho ? *ho : 0.0f;

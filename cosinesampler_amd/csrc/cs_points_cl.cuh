@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
     sm.weights(W);
     const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
-    ST *o = out + (int64_t)sm.n * d.C * d.P + sm.p;   // d.C: the caller's channel count (C is the padded one)
+    ST *o = out + (int64_t)sm.n * d.out_ns + sm.p;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count, C the padded one)
     float4 v[CQ][NC];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    ST *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
     float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const 
             rec[R::COEF + NC + a] = Dm[a];
         }
     }
-    ST *ggo = ggOut + (int64_t)sm.n * d.C * d.P + sm.p;
+    ST *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 o = zero4();

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     __syncthreads();
     const int n = blockIdx.y;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
-    ST *obase = out + (int64_t)n * d.C * d.P;   // d.C: the caller's channel count (template C is the padded one)
+    ST *obase = out + (int64_t)n * d.out_ns;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
     QuadSample qsv[CQ];
     float4 vv[CQ][4];
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
         }
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P, sm.p, d.P, sm.live, d.C, f.pair16);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.out_ns, sm.p, d.P, sm.live, d.C, f.pair16);
     if (sm.live) *reinterpret_cast<float2 *>(gGrid + sm.s * 2) = make_float2(rec[4 * 64 + lane], rec[5 * 64 + lane]);
 }
 
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void point_bbb(const float *__restrict__ icl, 
         *reinterpret_cast<float4 *>(row + 4 * q) = acc;   // over the (already flushed) gOut quad
     }
     __syncthreads();
-    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.C * d.P, sm.p, d.P, sm.live, d.C, f.pair16);
+    q_store_rows<CQ>(stage, STRIDE, ggOut + (int64_t)sm.n * d.out_ns, sm.p, d.P, sm.live, d.C, f.pair16);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -296,7 +296,7 @@ _FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST 
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_grad_input=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
-          go_owner=None, sum_n=False):
+          go_owner=None, sum_n=False, out_ns=None):
     """want_grad_input: the stage produces an input-shaped gradient (it scatters).  go_owner: the caller's tensor that
     `grad_output` was made from (itself unless the autograd layer converted the dtype): what the sorted copy in the plan
     is remembered by."""
@@ -347,7 +347,7 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
                 if not g_valid:
                     g_leave = int(ctx.reuse_grad_output or ctx._expected_count(owner) >= 2)
             layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
-                                          g_leave)
+                                          g_leave, 0 if out_ns is None else out_ns)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
@@ -508,6 +508,17 @@ def _group_ctx(ctx, input, a, b):
     return ent[1], ent[2]
 
 
+def _out_view(view, like, name):
+    """A caller-provided place for a written stream -- the channel range of a wider (N, C_total, ..., P) tensor that a channel
+    group's result goes to directly (no torch.cat afterwards): contiguous within one n, 16-byte aligned.  -> its n-stride, or
+    None when the view cannot be written in place (the caller then copies)."""
+    if view is None or tuple(view.shape) != tuple(like.shape) or view.dtype != like.dtype or view.device != like.device:
+        return None
+    if not view.shape[0] or not view[0].is_contiguous() or view.stride(0) < view[0].numel() or view.data_ptr() % 16:
+        return None
+    return view.stride(0)
+
+
 def _rng(t, a, b):
     return None if t is None else t[:, a:b]
 
@@ -579,7 +590,7 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
 
 
 def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners,
-                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True, go_owner=None):
+                      input_requires_grad, kernel, multicell, ctx=None, want_grad_input=True, go_owner=None, ggo_out=None):
     """-> (grad_input, grad_grid, grad_grad_out).  grad_out_input is only read when
     input_requires_grad (reference 2d.cu:654-656); grad_out_grid may be None (= zeros).
     want_grad_input=False (not in the reference): grad_input is not computed and comes back as None --
@@ -593,16 +604,20 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
         _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
         if input_requires_grad:
             _same(grad_out_input, input.shape, "grad_out_input", input.device)
-        gI, gG, gO = [], [], []
+        gI, gG = [], []
+        # every group writes its channels of grad_grad_out in place (cs_cotangent_layout.grad_grad_out_stride_n): no cat
+        ggO = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
         for a, b in groups:
             ig, cg = _group_ctx(ctx, input, a, b)
             ci = _rng(grad_out_input, a, b).contiguous() if input_requires_grad else None
             r = backward_backward(ci, grad_out_grid, ig, grid, _rng(grad_output, a, b), offset, padding_mode,
-                                  align_corners, input_requires_grad, kernel, multicell, cg, want_grad_input)
+                                  align_corners, input_requires_grad, kernel, multicell, cg, want_grad_input,
+                                  ggo_out=ggO[:, a:b])
             gI.append(r[0])
             gG.append(r[1])
-            gO.append(r[2])
-        return _cat(gI), _add(gG), torch.cat(gO, 1)
+            if r[2].data_ptr() != ggO[:, a:b].data_ptr():
+                ggO[:, a:b].copy_(r[2])
+        return _cat(gI), _add(gG), ggO
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     if input_requires_grad:
@@ -615,13 +630,15 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
     grad_input = torch.empty_like(input) if want_grad_input else None
     bc = grid_is_broadcast(input, grid)
     grad_grid = _grid_result(grid, shape[0], bc)
-    grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
+    out_ns = _out_view(ggo_out, grad_output, "grad_grad_out")
+    grad_grad_out = ggo_out if out_ns is not None else torch.empty(grad_output.shape, dtype=grad_output.dtype,
+                                                                   device=grad_output.device)
     _call("backward_backward", dim,
           [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
            _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
           want_grad_input=bool(want_grad_input), have_cI=grad_out_input is not None, go_ns=go_ns,
-          grad_output=grad_output, go_owner=go_owner)
+          grad_output=grad_output, go_owner=go_owner, out_ns=out_ns)
     return grad_input, _grid_reduce(grad_grid, bc), grad_grad_out
 
 
@@ -659,7 +676,7 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
 
 
 def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,
-              align_corners, kernel, multicell, ctx=None, go_owner=None):
+              align_corners, kernel, multicell, ctx=None, go_owner=None, ggo_out=None):
     """-> (grad_input, grad_grad_out) of the whole third backward (reference modules_2d.py:98-111):
     grad_input = K4.gInput + K3(gOut := grad_out_ggout, gOutInput := ones).gInput in one pass.
     grad_out_grid / grad_out_ggrid / grad_out_ggout may each be None (= zeros)."""
@@ -673,14 +690,16 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
         _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
         if grad_out_ggout is not None:
             _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
-        gI, gO = [], []
+        gI = []
+        ggO = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)   # written in place, group by group
         for a, b in groups:
             ig, cg = _group_ctx(ctx, input, a, b)
             r = bbb_fused(ig, grid, _rng(grad_output, a, b), grad_out_grid, grad_out_ggrid, _rng(grad_out_ggout, a, b),
-                          offset, padding_mode, align_corners, kernel, multicell, cg)
+                          offset, padding_mode, align_corners, kernel, multicell, cg, ggo_out=ggO[:, a:b])
             gI.append(r[0])
-            gO.append(r[1])
-        return torch.cat(gI, 1), torch.cat(gO, 1)
+            if r[1].data_ptr() != ggO[:, a:b].data_ptr():
+                ggO[:, a:b].copy_(r[1])
+        return torch.cat(gI, 1), ggO
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
@@ -691,12 +710,14 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
         ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
     kernel, _ = _stream_kernel(kernel, grad_output, grad_out_ggout)
     grad_input = torch.empty_like(input)
-    grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
+    out_ns = _out_view(ggo_out, grad_output, "grad_grad_out")
+    grad_grad_out = ggo_out if out_ns is not None else torch.empty(grad_output.shape, dtype=grad_output.dtype,
+                                                                   device=grad_output.device)
     _call("bbb_fused", dim,
           [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
            _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
           shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner)
+          want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner, out_ns=out_ns)
     return grad_input, grad_grad_out
 
 

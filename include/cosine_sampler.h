@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 11
+#define CS_ABI_VERSION 12
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -129,6 +129,10 @@ typedef struct cs_cotangent_layout {
      * called with sorted_grad_output_valid.  Worth it from the second use on; a stage that does not leave its copy does
      * not touch the one the plan holds. */
     int32_t leave_sorted_grad_output;
+    /* Elements between consecutive n of the stream the stage WRITES, grad_grad_out (second / third backward); 0 = contiguous
+     * (C*P).  Larger when grad_grad_out is a channel range of a wider (N, C_total, P) tensor -- how tables with more channels
+     * than the fast paths hold are run as channel groups without gathering the groups' results afterwards. */
+    int64_t grad_grad_out_stride_n;
 } cs_cotangent_layout;
 
 int cs_abi_version(void);
@@ -140,8 +144,9 @@ const char *cs_error_string(int code);
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI);
 
-/* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
+/* 1 if the summing kernels of CS_SUM_OVER_N are built for this problem, else 0 (the caller sums himself). */
 int cs2d_sum_over_n_supported(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners);
+/* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
 int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 
 /* Channels-last copy (N,spatial...,CP) of an (N,C,spatial...) tensor, CP = C padded with zero channels to 4, 8, 16 or 32
