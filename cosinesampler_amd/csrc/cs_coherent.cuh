@@ -52,10 +52,16 @@ struct Lay {
     static constexpr int NH = C > 16 ? C / 16 : 1;     // 16-channel halves (one accumulator tile each)
     static constexpr int PT = 66;                      // pitch of the channel-major cotangent rows [C][PT]: the matrix
                                                        // core's B reads (16 channels x 2 samples per half wave) hit 32 banks
-    static constexpr int ROWP = WN * C;                // floats per window row; 10 nodes: the four node rows a lane
-                                                       // reads (i, i+1, i+10, i+11) start in four different bank quarters
+#ifndef CS_COH_ROW_PAD
+#define CS_COH_ROW_PAD 4
+#endif
+    // floats per table-window row: 10 nodes + one 16-byte slot.  A lane's 16-byte reads of its node rows (ds_read_b128: 16
+    // lanes share the 64 banks) then fall on different slots for all 16 nodes of a quad's 4 x 4 block -- slot (4 lx + 9 ly) mod 16
+    // at C = 16 -- where the unpadded pitch put node (y+1, x) on the banks of node (y, x+2): samples that the multicell shift
+    // moved to the next cell collided with their neighbours' (rocprofv3: 56 of the 154 LDS cycles of a batch's 16 reads)
+    static constexpr int ROWP = WN * C + CS_COH_ROW_PAD;
     static constexpr int WIN = WNY * ROWP;
-    static constexpr int ROWA = ROWP + 16;             // row pitch of the accumulator window: block rows r, r+1 of the
+    static constexpr int ROWA = WN * C + 16;           // row pitch of the accumulator window: block rows r, r+1 of the
     static constexpr int WINA = WNY * ROWA;            // matrix core's result (half a wave) land 16 banks apart
 };
 
@@ -152,8 +158,8 @@ struct Windows {
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = i * 64 + lane;
-            if (idx < WNY * Q) reinterpret_cast<float4 *>(tw)[idx] = v[i];
+            const int idx = i * 64 + lane, iy = idx / Q, c4 = idx - iy * Q;
+            if (idx < WNY * Q) *reinterpret_cast<float4 *>(tw + iy * L::ROWP + 4 * c4) = v[i];
         }
     }
     // AW -> the channels-last accumulator, WN*C contiguous floats per row: whole-line float atomics; AW is left zero
