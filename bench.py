@@ -12,9 +12,12 @@ N=16 C=16 H=W=256, P=2^20 points PER GPU (configs[1]; configs[4] = the same per-
 One step = one pass of the whole hot path over one batch of synthetic, HBM-resident inputs:
     forward (K1) -> the point plan of the grid (shared by the backward stages, rebuilt every step) ->
     backward (K2: grad_input + grad_grid) -> backward_backward (K3, gOutInput absent)
-    -> fused third backward (K4 + the reference's extra K3), the three input-shaped gradients summed into one
-    buffer; for N>1 each of them is first summed over the ranks by an RCCL all-reduce that starts, asynchronously,
-    as soon as its stage is enqueued (cosinesampler_amd.dist.GradReducer) -- the step waits once, at its end.
+    -> fused third backward (K4 + the reference's extra K3).  What the step delivers of the three input-shaped
+    gradients is their SUM (what autograd accumulates into cells.grad): the stages add into one step accumulator
+    (ops.StepContext(accumulate=True), cs_cotangent_layout.accumulate_grad_input) -- one clear and one layout conversion
+    per step -- and for N>1 that sum is all-reduced ONCE over the ranks (RCCL; --reduce once, the default).
+    --reduce per_stage keeps the three gradients apart and starts an asynchronous all-reduce for each as soon as its
+    stage is enqueued (cosinesampler_amd.dist.GradReducer), the step waiting once at its end.
 All calls go through the C ABI (cosinesampler_amd.ops -> libcosine_sampler_hip.so).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the slowest stage kernel(s) (HIP-event time on
@@ -237,9 +240,10 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 20, help="P per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-helmholtz", action="store_true", help="skip the extra autograd-driven PIXEL step timing")
-    ap.add_argument("--reduce", choices=["per_stage", "once"], default="per_stage",
-                    help="N>1: all-reduce every stage's input-shaped gradient as soon as it is enqueued (3 x 64 MiB, overlapped) "
-                         "or accumulate locally and all-reduce once per step (1 x 64 MiB, SURVEY 8e)")
+    ap.add_argument("--reduce", choices=["per_stage", "once"], default="once",
+                    help="N>1: the stages add into one step accumulator and its sum is all-reduced once per step (1 x 64 MiB, "
+                         "SURVEY 8e; default) or every stage's input-shaped gradient is kept apart and all-reduced as soon as "
+                         "it is enqueued (3 x 64 MiB, overlapped, then summed)")
     ap.add_argument("--rccl-alone", action="store_true",
                     help="with one rank: still create the RCCL process group and run the gradient all-reduces through it")
     args = ap.parse_args()
@@ -283,6 +287,8 @@ def main():
     hG = torch.randn(N, 1, P, 2, device=dev)
     off = multicell_offset(N, mc, dev)
     acc = torch.zeros_like(cells)
+    # one step accumulator for the three input-shaped gradients unless the per-stage reduce schedule needs them apart
+    accumulate = not (use_dist and args.reduce == "per_stage")
 
     stage_names = ["forward", "backward", "backward_backward", "bbb_fused"]
     ev = []
@@ -293,7 +299,7 @@ def main():
         # A fresh StepContext every step: the channels-last copy of `cells` and the point plan of
         # `grid` are rebuilt inside the timed region each step (forward pays the copy, backward the
         # plan), exactly as one CosineSampler2d.apply + its backward chain would.
-        sc = ops.StepContext(points_order=order)
+        sc = ops.StepContext(points_order=order, accumulate=accumulate)
         # every input-shaped gradient starts its sum over the ranks the moment its stage has been enqueued (RCCL's own
         # stream, behind the producing kernels) and the step waits once, at the end: only the last one is exposed
         red = GradReducer(even_alone=args.rccl_alone, enabled=reduce and use_dist, schedule=args.reduce)
@@ -309,20 +315,25 @@ def main():
         if record:
             e[2].record()
         gI, gG = ops.backward(gOut, cells, grid, off, pad, align, True, kern, mc, ctx=sc)
-        red.push(gI)
+        if not accumulate:
+            red.push(gI)
         if record:
             e[3].record()
         bbI, bbG, bbO = ops.backward_backward(None, cG, cells, grid, gOut, off, pad, align, False, kern, mc, ctx=sc)
-        red.push(bbI)
+        if not accumulate:
+            red.push(bbI)
         if record:
             e[4].record()
         tI, tO = ops.bbb_fused(cells, grid, gOut, cG, hG, hO, off, pad, align, kern, mc, ctx=sc)
-        red.push(tI)
+        if accumulate:                   # the sum of the three gradients, in the caller's layout (the third stage's span
+            total = red.push(sc.grad_input_sum())          # pays the one conversion), then ONE all-reduce over the ranks
+        else:
+            red.push(tI)
         if record:
             e[5].record()
             ev.append(e)
-        red.finish(out=acc)              # acc = sum over stages (and ranks) of the input-shaped gradients
-        return out, gG, bbG, bbO, tO
+        total = red.finish(out=None if accumulate else acc)   # = sum over stages (and ranks) of the input-shaped gradients
+        return out, gG, bbG, bbO, tO, total
 
     def timed(steps, record, reduce=True, **kw):
         torch.cuda.synchronize()

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/cosine_sampler.h"
 #include "cs_kernels_direct.cuh"
@@ -21,6 +23,14 @@ namespace tl = cs::tiled;
 
 constexpr int kBlock = 256;
 std::atomic<int> g_force_path{0};  // cs_debug_force_path
+// The testing knobs act only in a process that asked for them: COSINESAMPLER_DEBUG=1 in the environment, read once.
+bool debug_enabled() {
+    static const bool on = [] {
+        const char *e = std::getenv("COSINESAMPLER_DEBUG");
+        return e && std::strcmp(e, "1") == 0;
+    }();
+    return on;
+}
 
 struct Problem {
     Dims d;
@@ -30,6 +40,7 @@ struct Problem {
     int sdt;      // element type of the channel-major streams: 0 fp32, 1 half, 2 bfloat16 (CS_STREAM_*)
     bool coherent;   // CS_POINTS_COHERENT: the caller says consecutive points share cells
     bool sum_n;      // CS_SUM_OVER_N: shared points and cotangents, per-point results summed over the tables
+    int acc_kind;    // cs_cotangent_layout.accumulate_grad_input: grad_input is the caller's step accumulator (CS_ACC_*)
     hipStream_t stream;
     unsigned blocks;
 };
@@ -43,6 +54,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     const bool grid_bc = (kernel & CS_GRID_BROADCAST) != 0;
     pb.coherent = (kernel & CS_POINTS_COHERENT) != 0;
     pb.sum_n = (kernel & CS_SUM_OVER_N) != 0;
+    pb.acc_kind = CS_ACC_NONE;
     if (pb.sum_n && (!grid_bc || exact)) return CS_ERR_UNSUPPORTED;     // one set of points for every table; the reference's derivatives
     kernel &= ~(CS_KERNEL_EXACT_MIXED | CS_STREAM_F16 | CS_STREAM_BF16 | CS_GRID_BROADCAST | CS_POINTS_COHERENT | CS_SUM_OVER_N);
     if (padding_mode < 0 || padding_mode > 2 || kernel < 0 || kernel > 2) return CS_ERR_INVALID;
@@ -421,7 +433,7 @@ struct Carve {
 };
 
 size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int have_cl, int have_plan,
-                       int have_cI, bool coherent) {
+                       int have_cI, bool coherent, bool accumulate) {
     const int64_t CP = cpad(C);
     size_t T = align256((size_t)N * CP * H * W * 4);
     size_t S = (size_t)N * P;
@@ -429,7 +441,7 @@ size_t tiled_workspace(int stage, int64_t N, int64_t C, int64_t H, int64_t W, in
     if (!have_cl) need += T;
     if (stage == CS_STAGE_FORWARD) return need;
     if (coherent && !(stage == CS_STAGE_BACKWARD_BACKWARD && have_cI))   // no plan, no records: the channels-last accumulator is all
-        return need + T;
+        return need + (accumulate ? 0 : T);                              // (... and with a step accumulator it is the caller's)
     if (!have_plan) need += plan_layout(N, C, H, W, P).bytes;
     if (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI) need += T;
     need += align256(S * (size_t)(stage == CS_STAGE_BBB_FUSED ? tl::row2((int)CP) : tl::row1((int)CP)) * 4);   // fat rows
@@ -541,14 +553,29 @@ int sum_n_check(const Problem &pb, bool has_gOut, bool has_hO) {
     return CS_OK;
 }
 // the zeroed channels-last accumulator the coherent kernels add into
-int coherent_accumulator(const Problem &pb, Carve &ws, float *&acc) {
+// (cs_cotangent_layout.accumulate_grad_input: the caller's `grad_input` IS that accumulator, already holding the sums of
+// the step's earlier stages -- nothing to clear here and nothing to unpack afterwards)
+int coherent_accumulator(const Problem &pb, Carve &ws, float *grad_input, float *&acc) {
+    if (pb.acc_kind == CS_ACC_NCHW) return CS_ERR_UNSUPPORTED;
+    if (pb.acc_kind == CS_ACC_CHANNELS_LAST) {
+        acc = grad_input;
+        return CS_OK;
+    }
     const int64_t T = (int64_t)pb.d.N * cpad(pb.d.C) * pb.d.vol;
     acc = (float *)ws.take((size_t)T * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
     return zero_async(acc, T, pb.stream);
 }
 int coherent_finish(const Problem &pb, const float *acc, float *grad_input) {
+    if (pb.acc_kind) return CS_OK;
     return unpack_cl(acc, grad_input, pb.d.N, pb.d.C, cpad(pb.d.C), pb.d.vol, pb.stream);
+}
+// the walkers / the wave-per-cell kernel add their sums to NC[D]HW grad_input with float atomics: a step accumulator of
+// that layout is simply not cleared
+int walker_target(const Problem &pb, float *grad_input) {
+    if (pb.acc_kind == CS_ACC_CHANNELS_LAST) return CS_ERR_UNSUPPORTED;
+    if (pb.acc_kind == CS_ACC_NCHW) return CS_OK;
+    return zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
 }
 
 int tiled_backward(const Problem &pb, const float *gOut, const float *input, const float *grid, const float *offset,
@@ -564,7 +591,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     if (rc) return rc;
     if (coh) {
         float *acc = nullptr;
-        if (grad_input) rc = coherent_accumulator(pb, ws, acc);
+        if (grad_input) rc = coherent_accumulator(pb, ws, grad_input, acc);
         if (rc) return rc;
         rc = cs::coh::backward(coh_launch(pb), gOut, pr.icl, grid, offset, acc, grad_grid);
         return rc || !grad_input ? rc : coherent_finish(pb, acc, grad_input);
@@ -577,7 +604,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
     float *fat = (float *)ws.take((size_t)pb.d.S * tl::row1((int)cpad(pb.d.C)) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
-    rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    rc = walker_target(pb, grad_input);
     if (rc) return rc;
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
                                       (const ST *)gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
@@ -610,7 +637,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     }
     if (coh) {
         float *acc = nullptr;
-        if (gInput) rc = coherent_accumulator(pb, ws, acc);
+        if (gInput) rc = coherent_accumulator(pb, ws, gInput, acc);
         if (rc) return rc;
         rc = cs::coh::bb(coh_launch(pb), cG, pr.icl, grid, gOut, offset, acc, gGrid, ggOut);
         return rc || !gInput ? rc : coherent_finish(pb, acc, gInput);
@@ -622,7 +649,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     if (gInput) {
         fat = (float *)ws.take((size_t)pb.d.S * (lean ? 4 : tl::row1((int)cpad(pb.d.C))) * 4);
         if (!ws.ok()) return CS_ERR_WORKSPACE;
-        rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+        rc = walker_target(pb, gInput);
         if (rc) return rc;
     }
     const size_t shm = q_lds(tl::row1((int)cpad(pb.d.C)), 12);
@@ -652,7 +679,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     if (rc) return rc;
     if (coh) {
         float *acc;
-        rc = coherent_accumulator(pb, ws, acc);
+        rc = coherent_accumulator(pb, ws, gInput, acc);
         if (rc) return rc;
         rc = cs::coh::bbb(coh_launch(pb), pr.icl, grid, gOut, cG, hG, hO, offset, acc, ggOut);
         return rc ? rc : coherent_finish(pb, acc, gInput);
@@ -660,7 +687,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
     const bool lean = hO && g_sorted && pr.plan_is_callers && !pr.plan.dense;   // see tiled_bb
     float *fat = (float *)ws.take((size_t)pb.d.S * (lean ? tl::row3((int)cpad(pb.d.C)) : tl::row2((int)cpad(pb.d.C))) * 4);
     if (!ws.ok()) return CS_ERR_WORKSPACE;
-    rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
+    rc = walker_target(pb, gInput);
     if (rc) return rc;
     if (lean) {
         const size_t shm = q_lds(tl::row3((int)cpad(pb.d.C)), 0);
@@ -1128,6 +1155,8 @@ void pair_streams(Problem &pb, std::initializer_list<const void *> streams) {
 
 }  // namespace
 
+static bool misaligned_ptr(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
 extern "C" {
 
 int cs_abi_version(void) { return CS_ABI_VERSION; }
@@ -1142,8 +1171,45 @@ const char *cs_error_string(int code) {
     }
 }
 
-void cs_debug_force_path(int mode) { g_force_path.store(mode, std::memory_order_relaxed); }
-void cs_debug_coherent_tuning(int samples_per_wave, int waves_per_block) { cs::coh::set_chunk(samples_per_wave, waves_per_block); }
+int cs_debug_force_path(int mode) {
+    if (!debug_enabled()) return 0;
+    g_force_path.store(mode, std::memory_order_relaxed);
+    return 1;
+}
+int cs_debug_coherent_tuning(int samples_per_wave, int ablation_bits) {
+    if (!debug_enabled()) return 0;
+    cs::coh::set_chunk(samples_per_wave, ablation_bits);
+    return 1;
+}
+
+int cs_accumulator_kind(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int kernel) {
+    if (dim != 2 || N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0) return CS_ACC_NONE;
+    Problem pb;
+    if (make_problem(pb, 2, N, C, 1, H, W, P, 0, 1, kernel, 1, nullptr)) return CS_ACC_NONE;
+    if (pb.f.exact || !tiled_applies(2, N, C, H, W, P)) return CS_ACC_NONE;
+    return coherent_applies(pb) ? CS_ACC_CHANNELS_LAST : CS_ACC_NCHW;
+}
+size_t cs_accumulator_bytes(int dim, int kind, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
+    const int64_t vol = (dim == 3 ? D : 1) * H * W;
+    if (kind == CS_ACC_NCHW) return (size_t)N * C * vol * 4;
+    if (kind == CS_ACC_CHANNELS_LAST) return (size_t)N * cpad(C) * vol * 4;
+    return 0;
+}
+int cs_accumulator_finish(int dim, int kind, const float *acc, float *grad_input, int64_t N, int64_t C, int64_t D,
+                          int64_t H, int64_t W, void *stream) {
+    if ((dim != 2 && dim != 3) || N < 0 || C < 0 || H < 1 || W < 1 || (dim == 3 && D < 1)) return CS_ERR_INVALID;
+    const int64_t vol = (dim == 3 ? D : 1) * H * W;
+    if (N * C == 0) return CS_OK;
+    if (!acc || !grad_input || misaligned_ptr(acc) || misaligned_ptr(grad_input)) return CS_ERR_INVALID;
+    if (kind == CS_ACC_NCHW) {
+        if (acc == grad_input) return CS_OK;
+        hipError_t e = hipMemcpyAsync(grad_input, acc, (size_t)N * C * vol * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return e == hipSuccess ? CS_OK : (int)e;
+    }
+    if (kind != CS_ACC_CHANNELS_LAST || N > 65535) return CS_ERR_INVALID;
+    return unpack_cl(acc, grad_input, N, C, cpad(C), vol, (hipStream_t)stream);
+}
 
 size_t cs_sort_points_bytes(int64_t P) { return cs::sort::workspace_bytes(P); }
 int cs2d_sort_points(const float *points, float *sorted_points, int32_t *perm, int64_t P, int64_t H, int64_t W,
@@ -1175,7 +1241,8 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || (dim == 3 && D <= 0)) return 0;
     const bool coherent = (stage & CS_STAGE_POINTS_COHERENT) != 0 && dim == 2 && W <= cs::coh::MAX_SIZE_HOST &&
                           H <= cs::coh::MAX_SIZE_HOST && g_force_path.load(std::memory_order_relaxed) != 5;
-    stage &= ~CS_STAGE_POINTS_COHERENT;
+    const bool accumulate = (stage & CS_STAGE_ACCUMULATE) != 0;
+    stage &= ~(CS_STAGE_POINTS_COHERENT | CS_STAGE_ACCUMULATE);
     if (stage & CS_STAGE_NO_GRAD_INPUT) {
         // grad_input == NULL: nothing is scattered -- no plan, no rows, no accumulator; what is left is the
         // channels-last copy of the table (and of grad_out_input, when the second backward carries one)
@@ -1184,7 +1251,7 @@ size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, i
         const size_t T = cs_pack_bytes(dim, N, C, D, H, W, P);
         return (have_input_cl ? 0 : T) + (stage == CS_STAGE_BACKWARD_BACKWARD && have_cI ? T : 0);
     }
-    if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI, coherent);
+    if (tiled_applies(dim, N, C, H, W, P)) return tiled_workspace(stage, N, C, H, W, P, have_input_cl, have_plan, have_cI, coherent, accumulate);
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
     if (rows_cl_applies(dim, N, C, P, vol)) {
         if (dense3_applies(N, C, D, H, W, P)) return dense3_workspace(stage, N, C, D, H, W, P, have_input_cl, have_plan, have_cI);
@@ -1300,6 +1367,10 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         }                                                                                            \
         g_sorted = layout->sorted_grad_output_valid != 0;                                            \
         g_leave = layout->leave_sorted_grad_output != 0;                                             \
+        if (layout->accumulate_grad_input < 0 || layout->accumulate_grad_input > CS_ACC_CHANNELS_LAST) return CS_ERR_INVALID; \
+        pb.acc_kind = layout->accumulate_grad_input;                                                 \
+        /* only the 2D fast paths add into a caller-held accumulator (cs_accumulator_kind says so beforehand) */ \
+        if (pb.acc_kind && !tiled) return CS_ERR_UNSUPPORTED;                                        \
     }
 
 // the alignment contract of include/cosine_sampler.h: the kernels issue 8-byte accesses on grid-shaped tensors and
@@ -1367,6 +1438,7 @@ int cs2d_backward_backward(const float *grad_out_input, const float *grad_out_gr
     // (the row-atomic scatter needs C a power of two >= 2: C = 1, 3 keep the direct kernel, which scatters itself)
     pair_streams(pb, {grad_output, grad_grad_out});
     const bool exact_ci = tiled && pb.f.exact && grad_out_input;
+    if (pb.acc_kind && exact_ci) return CS_ERR_UNSUPPORTED;   // that call leaves the fast path: it defines, it cannot add
     const bool via_rows = rows || (exact_ci && log2_exact(C) >= 1 && N <= 65535);
     if (pb.sdt && (!tiled || exact_ci)) return CS_ERR_UNSUPPORTED;
     if (tiled && !exact_ci)
@@ -1552,6 +1624,7 @@ int cs2d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     int rc = make_problem(pb, 2, N, C, 1, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
     bool g_sorted = false, g_leave = false;
+    const bool tiled = false;     // (this entry point produces no input-shaped gradient: nothing to accumulate)
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)
@@ -1568,6 +1641,7 @@ int cs3d_bbb_grid(const float *input, const float *grid, const float *grad_outpu
     int rc = make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, kernel, multicell, stream);
     if (rc) return rc;
     bool g_sorted = false, g_leave = false;
+    const bool tiled = false;     // (this entry point produces no input-shaped gradient: nothing to accumulate)
     CS_LAYOUT()
     (void)g_sorted; (void)g_leave;
     CS_NEED(input, grid, grad_output, grad_out_grid, offset, grad_grid3)

@@ -46,6 +46,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { FWD = 0, BWD = 1, BB = 2, BBB = 3 };
 
+// batches of stream loads a wave keeps in flight (register sets); the summing kernels' chunk is 64 * depth(mode)
+#ifndef CS_COH_DEPTH_BWD
+#define CS_COH_DEPTH_BWD 2
+#endif
+__host__ __device__ constexpr int depth(int mode) { return mode == FWD ? 4 : mode == BWD ? CS_COH_DEPTH_BWD : 2; }
+
 template <int C>
 struct Lay {
     static constexpr int CQ = C / 4;
@@ -334,8 +340,8 @@ struct Args {
 // ago]  geometry  ->  LDS, vector and matrix work only  ->  the set's next loads go out, then this batch's outputs leave.
 // The windows' global traffic (table rows in, atomics out) happens when the wave moves to another quad row: once per
 // ~4 batches of an ordered set.
-// `dbg`: experiments only (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window flush, 4 no per-sample products,
-// 32 no table-window loads, 64 no scatter operands written to LDS.
+// `dbg`: experiments only, compiled in with -DCS_COH_DEBUG (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window
+// flush, 4 no per-sample products, 32 no table-window loads, 64 no scatter operands written to LDS.
 // =====================================================================================================
 // COMMON: zeros padding with align_corners -- every BASELINE config and the reference's defaults -- as compile-time
 // constants: the padding variants are wave-uniform branches, but they cost scalar registers (the general kernels spill them
@@ -351,6 +357,9 @@ struct Args {
 template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST, bool COMMON = false, bool NSUM = false>
 __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
     Flags f = f_;
+#ifndef CS_COH_DEBUG
+    dbg = 0;      // the ablation switches (wrong results by design) exist only in experiment builds (-DCS_COH_DEBUG, tools/ab.sh)
+#endif
     if constexpr (COMMON) {
         f.pad = PAD_ZEROS;
         f.align = 1;
@@ -362,10 +371,7 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
     constexpr bool PROD = MODE == BWD || MODE == BB;     // needs the products input[q_a] . gOut
     constexpr bool OUTS = MODE != BWD;                   // produces a channel stream
     constexpr int ORD = MODE == FWD ? 0 : MODE == BWD ? 1 : 2;
-    #ifndef CS_COH_DEPTH_BWD
-#define CS_COH_DEPTH_BWD 2
-#endif
-    constexpr int DEPTH = MODE == FWD ? 4 : MODE == BWD ? CS_COH_DEPTH_BWD : 2;         // batches of stream loads in flight per wave
+    constexpr int DEPTH = depth(MODE);                   // batches of stream loads in flight per wave
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
     int n = NSUM ? 0 : blockIdx.y;

@@ -14,6 +14,9 @@ int launch_nsum(int mode, bool two, bool scat, const Launch &L, const Args &a, i
 namespace {
 
 std::atomic<int> g_dbg{0}, g_chunk{512}, g_wpb{1};
+#ifndef CS_COH_LDS_EXTRA
+#define CS_COH_LDS_EXTRA 0     // experiments (tools/ab.sh): unused LDS bytes per wave, to cap the waves a CU holds
+#endif
 
 int status() {
     hipError_t e = hipGetLastError();
@@ -69,7 +72,7 @@ int launch(const Launch &L, const Args &a) {
     if (L.sdt == 0 && L.f.pad == PAD_ZEROS && L.f.align) {     // fp32 streams, zeros padding, align_corners: the specialised kernels
         COH_KERNEL_(L.kernel, COH_CQ(L.cq, {
             using ST = float;
-            const size_t shm = (size_t)(g.block / 64) * wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4;
+            const size_t shm = (size_t)(g.block / 64) * (wave_floats<4 * CQ>(SCAT ? MODE : FWD) * 4 + CS_COH_LDS_EXTRA);
             rc = allow_lds(stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true>, shm);
             if (!rc) stage<KERNEL, CQ, MODE, TWO, SCAT, ST, true><<<g.grid, g.block, shm, L.stream>>>(a, L.d, L.f, g.chunk, g.dbg);
         }));

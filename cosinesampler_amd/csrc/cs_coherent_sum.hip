@@ -38,7 +38,7 @@ int allow_lds(K kernel, size_t bytes) {
 // specialisation): the PIXEL pattern; anything else is the caller's to sum (supported_nsum).
 template <int MODE, bool TWO, bool SCAT>
 int launch_one(const Launch &L, const Args &a, int dbg) {
-    const int chunk = 64 * (MODE == FWD ? 4 : 2);          // = 64 * DEPTH of the kernel
+    constexpr int chunk = 64 * depth(MODE);                // the kernel keeps exactly its DEPTH register sets: one chunk
     const int64_t waves = (L.d.P + chunk - 1) / chunk;
     int rc = 0;
     SUM_KERNEL(L.kernel, SUM_CQ(L.cq, {

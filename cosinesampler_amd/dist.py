@@ -44,11 +44,12 @@ class GradReducer(object):
     A step produces up to three of them (first, second and third backward), each ready long before the step ends
     (at config 2: 1.8, 3.0 and 4.7 ms into a 5.3 ms step).  Two schedules:
 
-    * `"per_stage"` (default): `push(g)` starts `g`'s sum over the ranks right away -- asynchronously, on the
+    * `"per_stage"`: `push(g)` starts `g`'s sum over the ranks right away -- asynchronously, on the
       communicator's own stream, ordered after the kernels that produced `g` -- and returns at once; `finish()` waits
       for every collective started so far (the current stream waits, the host does not) and adds them up.  Three 64 MiB
       all-reduces per step, two of them hidden behind the stages that follow; three times the xGMI bytes.
-    * `"once"`: `push` only remembers `g`; `finish()` adds the gradients up locally and runs ONE all-reduce on the sum
+    * `"once"` (bench.py's default, together with a step accumulator -- ops.StepContext(accumulate=True) -- so that
+      what is pushed is already the sum): `push` only remembers `g`; `finish()` adds the gradients up locally and runs ONE all-reduce on the sum
       (what SURVEY 8e words: "one sum all-reduce per training step on the accumulated cells.grad"); a third of the
       bytes, all of it exposed at the end of the step.
 
@@ -80,8 +81,8 @@ class GradReducer(object):
             if work is not None:
                 work.wait()            # stream-ordered for RCCL; blocks for gloo
         grads = [g for g, _ in self._pending]
-        if out is None:
-            total = grads[0].clone()
+        if out is None:          # (a single gradient -- a step accumulator's sum -- is returned as it is, no copy)
+            total = grads[0].clone() if len(grads) > 1 else grads[0]
             rest = grads[1:]
         elif len(grads) == 1:
             total = out.copy_(grads[0])

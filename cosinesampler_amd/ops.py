@@ -192,7 +192,7 @@ class StepContext(object):
     on every call, modules_2d.py:55-62, :89-95).  The autograd Functions create one context per forward call, so nothing
     outlives the graph it belongs to; pass `ctx=None` to let every stage work from scratch."""
 
-    def __init__(self, reuse_grad_output=True, points_order=None):
+    def __init__(self, reuse_grad_output=True, points_order=None, accumulate=False):
         self._cl = None
         self._cl_of = None
         self._pe = None                  # _PlanEntry
@@ -209,6 +209,59 @@ class StepContext(object):
         # (_sorted_go: _Held of the tensor whose sorted copy the plan holds -- kept with the plan, which may be shared)
         # 'coherent' / 'random' / None (= ops.points_order(), by default measured): do consecutive points share cells?
         self.points_order = points_order
+        # accumulate=True (a caller driving the stages of one step itself: bench.py, the reference's pybind use): what a
+        # training step wants from its backward stages is the SUM of their input-shaped gradients (the autograd engine
+        # adds them up into cells.grad; a multi-GPU step all-reduces that sum once).  The stages then ADD into one
+        # accumulator held here (cs_cotangent_layout.accumulate_grad_input) and return None in place of grad_input;
+        # grad_input_sum() hands the total over: one clear and one layout conversion per step instead of one per stage,
+        # and no adding passes.  A stage that cannot add natively (3D, channel groups, a path with the other accumulator
+        # layout) computes its gradient the plain way and it is added here with torch.
+        self.accumulate = bool(accumulate)
+        self._acc = None                 # [kind, buffer, shape of input, dim]
+        self._acc_extra = None
+        self.acc_native = self.acc_fallback = 0     # how many stages added natively / through the fallback (tests)
+
+    def _acc_target(self, lib, dim, input, shape, P, kernel):
+        """-> the CS_ACC_* kind this stage can add with into the step's accumulator (made on first use), or 0"""
+        D = shape[2] if dim == 3 else 1
+        kind = lib.cs_accumulator_kind(dim, shape[0], shape[1], D, shape[-2], shape[-1], P, int(kernel))
+        if not kind:
+            return 0
+        if self._acc is None:
+            if kind == _lib.ACC_NCHW:        # the caller's own layout: the accumulator IS the final tensor
+                buf = torch.zeros_like(input)
+            else:
+                nbytes = lib.cs_accumulator_bytes(dim, kind, shape[0], shape[1], D, shape[-2], shape[-1])
+                buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=input.device)
+            self._acc = [kind, buf, tuple(input.shape), dim]
+        a = self._acc
+        if a[0] != kind or a[2] != tuple(input.shape) or a[1].device != input.device:
+            return 0
+        return kind
+
+    def _add_extra(self, grad_input):
+        if grad_input is not None:
+            self._acc_extra = grad_input if self._acc_extra is None else self._acc_extra.add_(grad_input)
+
+    def grad_input_sum(self):
+        """The sum of the input-shaped gradients of every backward stage run with this (accumulating) context since the
+        last call, in the caller's (N,C,[D,]H,W) layout; None if there was none.  Resets the accumulator."""
+        total = None
+        if self._acc is not None:
+            kind, buf, shape, dim = self._acc
+            if kind == _lib.ACC_NCHW:
+                total = buf
+            else:
+                total = torch.empty(shape, dtype=torch.float32, device=buf.device)
+                D = shape[2] if dim == 3 else 1
+                with torch.cuda.device(buf.device):
+                    _lib.check(_lib.load().cs_accumulator_finish(
+                        dim, kind, buf.data_ptr(), total.data_ptr(), shape[0], shape[1], D, shape[-2], shape[-1],
+                        torch.cuda.current_stream(buf.device).cuda_stream), "cs_accumulator_finish")
+        if self._acc_extra is not None:
+            total = self._acc_extra if total is None else total.add_(self._acc_extra)
+        self._acc = self._acc_extra = None
+        return total
 
     @property
     def _sorted_go(self):
@@ -294,12 +347,25 @@ _force_mode = 0
 _FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST | _lib.POINTS_COHERENT | _lib.SUM_OVER_N
 
 
+# number of C-ABI calls by stage, and how many of them scattered (produced an input-shaped gradient): a rocprof-free way for
+# tests to see that a graph ran the stages it should (e.g. that the autograd layer skipped the scatters nobody asked for)
+call_counts = {}
+
+
+def _count(stage, scattered):
+    c = call_counts.setdefault(stage, [0, 0])
+    c[0] += 1
+    c[1] += int(bool(scattered))
+
+
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
           grid=None, offset=None, want_grad_input=False, have_cI=False, go_ns=None, ho_ns=None, grad_output=None,
-          go_owner=None, sum_n=False, out_ns=None):
-    """want_grad_input: the stage produces an input-shaped gradient (it scatters).  go_owner: the caller's tensor that
-    `grad_output` was made from (itself unless the autograd layer converted the dtype): what the sorted copy in the plan
-    is remembered by."""
+          go_owner=None, sum_n=False, out_ns=None, gi_index=None, _define=False):
+    """want_grad_input: the stage produces an input-shaped gradient (it scatters); it is allocated here (ptrs[gi_index]
+    is its place in the argument list) and returned -- or, with an accumulating context, added to the step's accumulator
+    and None is returned.  go_owner: the caller's tensor that `grad_output` was made from (itself unless the autograd layer
+    converted the dtype): what the sorted copy in the plan is remembered by."""
+    kernel_in = kernel
     if not isinstance(kernel, int) or (kernel & ~_FLAGS) not in (0, 1, 2):
         # the reference's kernel_enum returns None for unknown names and pybind then rejects it
         raise TypeError("kernel enum must be 0 (cosine), 1 (linear) or 2 (smooth-step), optionally | EXACT_MIXED, "
@@ -330,6 +396,18 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
             stage_id |= _lib.STAGE_NO_GRAD_INPUT       # grad_input is not wanted: no plan, no scatter scratch
         if coherent:
             stage_id |= _lib.STAGE_POINTS_COHERENT
+        # the input-shaped gradient: a fresh tensor the call defines, or the step's accumulator it adds to
+        grad_input, acc_kind = None, 0
+        if want_grad_input:
+            ptrs = list(ptrs)
+            if ctx is not None and ctx.accumulate and not _define:
+                acc_kind = ctx._acc_target(lib, dim, input, shape, P, kernel)
+            if acc_kind:
+                ptrs[gi_index] = ctx._acc[1].data_ptr()
+                stage_id |= _lib.STAGE_ACCUMULATE
+            else:
+                grad_input = torch.empty_like(input)
+                ptrs[gi_index] = grad_input.data_ptr()
         need = lib.cs_workspace_bytes(dim, stage_id, shape[0], shape[1], D, shape[-2], shape[-1], P,
                                       int(cl is not None), int(plan is not None), int(have_cI))
         ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
@@ -347,13 +425,27 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
                 if not g_valid:
                     g_leave = int(ctx.reuse_grad_output or ctx._expected_count(owner) >= 2)
             layout = _lib.CotangentLayout(CP if go_ns is None else go_ns, CP if ho_ns is None else ho_ns, g_valid,
-                                          g_leave, 0 if out_ns is None else out_ns)
+                                          g_leave, 0 if out_ns is None else out_ns, acc_kind, 0)
             tail = (layout,) + tail
         rc = fn(*ptrs, *shape, P, int(padding_mode), int(bool(align_corners)), int(kernel), int(bool(multicell)),
                 *tail)
+    if rc == _lib.ERR_UNSUPPORTED and acc_kind:
+        # this stage's path keeps its sums in the other layout (e.g. the general second backward with grad_out_input in
+        # a step on the coherent kernels); nothing has been written: run it the plain way and add the result below
+        return _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel_in, multicell, device, ctx, input, grid,
+                     offset, want_grad_input, have_cI, go_ns, ho_ns, grad_output, go_owner, sum_n, out_ns, gi_index, True)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
+    _count(stage, want_grad_input)
     if g_leave:   # the plan now holds this one's sorted copy: remember whose, and keep it alive
         ctx._sorted_go = _Held(owner)
+    if want_grad_input and ctx is not None and ctx.accumulate:
+        if acc_kind:
+            ctx.acc_native += 1
+        else:
+            ctx.acc_fallback += 1
+            ctx._add_extra(grad_input)
+        return None
+    return grad_input
 
 
 # ---- the order of the points ------------------------------------------------------------------------------------
@@ -458,9 +550,11 @@ def force_path(mode):
     3 = 2 without the wave-per-cell kernel for crowded tables, 4 = 2 without the re-use of the sorted grad_output copy
     between the stages of a step, 5 = 0 with the coherent-points hint ignored, 6 = 2 with the two-reads pack of 3D tables."""
     global _force_epoch, _force_mode
+    if not _lib.load().cs_debug_force_path(int(mode)):
+        raise RuntimeError("the testing knobs of libcosine_sampler_hip.so are inert in this process: start it with "
+                           "COSINESAMPLER_DEBUG=1 in the environment (tests/conftest.py does)")
     _force_epoch += 1
     _force_mode = int(mode)
-    _lib.load().cs_debug_force_path(int(mode))
 
 
 def out_shape(input, grid):
@@ -534,6 +628,15 @@ def _add(parts):
     return out
 
 
+def _grouped(ctx, grad_input):
+    """the input-shaped gradient of a table run as channel groups: returned, or (accumulating context) added to the step's sum"""
+    if ctx is not None and ctx.accumulate and grad_input is not None:
+        ctx.acc_fallback += 1
+        ctx._add_extra(grad_input)
+        return None
+    return grad_input
+
+
 def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx=None, out_dtype=None):
     """out_dtype (not in the reference's signature): torch.float16 / torch.bfloat16 to have `output` written in that
     type by the kernel (fast paths only: half_streams_ok); default fp32."""
@@ -560,7 +663,8 @@ def forward(input, grid, offset, padding_mode, align_corners, kernel, multicell,
 def backward(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
              ctx=None, go_owner=None):
     """-> (grad_input | None, grad_grid); grad_input is None when input_requires_grad is False
-    (the reference returns an undefined Tensor, 2d.cpp:73-79)."""
+    (the reference returns an undefined Tensor, 2d.cpp:73-79) -- and, in every backward stage, when `ctx` accumulates
+    (StepContext(accumulate=True): the gradient has been added to the step's accumulator, ctx.grad_input_sum())."""
     if go_owner is None:
         go_owner = grad_output
     grad_output, input, grid = _al(grad_output, input, grid)
@@ -575,17 +679,16 @@ def backward(grad_output, input, grid, offset, padding_mode, align_corners, inpu
                          kernel, multicell, cg)
             gI.append(r[0])
             gG.append(r[1])
-        return _cat(gI), _add(gG)
+        return _grouped(ctx, _cat(gI)), _add(gG)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     kernel, _ = _stream_kernel(kernel, grad_output)
-    grad_input = torch.empty_like(input) if input_requires_grad else None
     bc = grid_is_broadcast(input, grid)
     grad_grid = _grid_result(grid, shape[0], bc)
-    _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input),
-                            _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell, input.device,
-          ctx, input, grid, offset, want_grad_input=bool(input_requires_grad), go_ns=go_ns, grad_output=grad_output,
-          go_owner=go_owner)
+    grad_input = _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), None,
+                                         _ptr(grad_grid)], shape, P, padding_mode, align_corners, kernel, multicell,
+                       input.device, ctx, input, grid, offset, want_grad_input=bool(input_requires_grad), go_ns=go_ns,
+                       grad_output=grad_output, go_owner=go_owner, gi_index=4)
     return grad_input, _grid_reduce(grad_grid, bc)
 
 
@@ -617,7 +720,7 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
             gG.append(r[1])
             if r[2].data_ptr() != ggO[:, a:b].data_ptr():
                 ggO[:, a:b].copy_(r[2])
-        return _cat(gI), _add(gG), ggO
+        return _grouped(ctx, _cat(gI)), _add(gG), ggO
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     if input_requires_grad:
@@ -627,18 +730,17 @@ def backward_backward(grad_out_input, grad_out_grid, input, grid, grad_output, o
     if grad_out_grid is not None:
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     kernel, _ = _stream_kernel(kernel, grad_output)
-    grad_input = torch.empty_like(input) if want_grad_input else None
     bc = grid_is_broadcast(input, grid)
     grad_grid = _grid_result(grid, shape[0], bc)
     out_ns = _out_view(ggo_out, grad_output, "grad_grad_out")
     grad_grad_out = ggo_out if out_ns is not None else torch.empty(grad_output.shape, dtype=grad_output.dtype,
                                                                    device=grad_output.device)
-    _call("backward_backward", dim,
-          [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
-           _ptr(grad_input), _ptr(grad_grid), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=bool(want_grad_input), have_cI=grad_out_input is not None, go_ns=go_ns,
-          grad_output=grad_output, go_owner=go_owner, out_ns=out_ns)
+    grad_input = _call("backward_backward", dim,
+                       [_ptr(grad_out_input), _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset),
+                        None, _ptr(grad_grid), _ptr(grad_grad_out)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=bool(want_grad_input), have_cI=grad_out_input is not None, go_ns=go_ns,
+                       grad_output=grad_output, go_owner=go_owner, out_ns=out_ns, gi_index=6)
     return grad_input, _grid_reduce(grad_grid, bc), grad_grad_out
 
 
@@ -659,19 +761,18 @@ def backward_backward_backward(input, grid, grad_output, grad_out_grid, grad_out
                                            padding_mode, align_corners, input_requires_grad, kernel, multicell, cg)
             gI.append(r[0])
             gO.append(r[1])
-        return torch.cat(gI, 1), torch.cat(gO, 1)
+        return _grouped(ctx, torch.cat(gI, 1)), torch.cat(gO, 1)
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
     _same(grad_out_ggrid, grid.shape, "grad_out_ggrid", input.device)
     kernel, _ = _stream_kernel(kernel, grad_output)
-    grad_input = torch.empty_like(input)
     grad_grad_out = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
-    _call("backward_backward_backward", dim,
-          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
-           _ptr(grad_input), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=True, go_ns=go_ns, grad_output=grad_output, go_owner=go_owner)
+    grad_input = _call("backward_backward_backward", dim,
+                       [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(offset),
+                        None, _ptr(grad_grad_out)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=True, go_ns=go_ns, grad_output=grad_output, go_owner=go_owner, gi_index=6)
     return grad_input, grad_grad_out
 
 
@@ -699,7 +800,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
             gI.append(r[0])
             if r[1].data_ptr() != ggO[:, a:b].data_ptr():
                 ggO[:, a:b].copy_(r[1])
-        return torch.cat(gI, 1), ggO
+        return _grouped(ctx, torch.cat(gI, 1)), ggO
     _offset_ok(offset, shape[0], input.device)
     go_ns = _same(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     for t, nm in ((grad_out_grid, "grad_out_grid"), (grad_out_ggrid, "grad_out_ggrid")):
@@ -709,15 +810,15 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
     if grad_out_ggout is not None:
         ho_ns = _same(grad_out_ggout, grad_output.shape, "grad_out_ggout", input.device, stream=True)
     kernel, _ = _stream_kernel(kernel, grad_output, grad_out_ggout)
-    grad_input = torch.empty_like(input)
     out_ns = _out_view(ggo_out, grad_output, "grad_grad_out")
     grad_grad_out = ggo_out if out_ns is not None else torch.empty(grad_output.shape, dtype=grad_output.dtype,
                                                                    device=grad_output.device)
-    _call("bbb_fused", dim,
-          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
-           _ptr(grad_out_ggout), _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner, out_ns=out_ns)
+    grad_input = _call("bbb_fused", dim,
+                       [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid),
+                        _ptr(grad_out_ggout), _ptr(offset), None, _ptr(grad_grad_out)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=True, go_ns=go_ns, ho_ns=ho_ns, grad_output=grad_output, go_owner=go_owner,
+                       out_ns=out_ns, gi_index=7)
     return grad_input, grad_grad_out
 
 
@@ -786,11 +887,10 @@ def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners
         return backward(_one(grad_output, shape[0]), input, grid, offset, padding_mode, align_corners, input_requires_grad,
                         kernel, multicell, ctx)
     _offset_ok(offset, shape[0], input.device)
-    grad_input = torch.empty_like(input) if input_requires_grad else None
     grad_grid = torch.empty_like(grid)
-    _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), _ptr(grad_input), _ptr(grad_grid)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=bool(input_requires_grad), go_ns=0, grad_output=grad_output, sum_n=True)
+    grad_input = _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), None, _ptr(grad_grid)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=bool(input_requires_grad), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=4)
     return grad_input, grad_grid
 
 
@@ -807,14 +907,13 @@ def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, pad
                                         align_corners, False, kernel, multicell, ctx, want_grad_input)
         return gI, gG, ggO.sum(0, keepdim=True)
     _offset_ok(offset, shape[0], input.device)
-    grad_input = torch.empty_like(input) if want_grad_input else None
     grad_grid = torch.empty_like(grid)
     grad_grad_out = torch.empty_like(grad_output)
-    _call("backward_backward", dim,
-          [None, _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset), _ptr(grad_input),
-           _ptr(grad_grid), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=bool(want_grad_input), go_ns=0, grad_output=grad_output, sum_n=True)
+    grad_input = _call("backward_backward", dim,
+                       [None, _ptr(grad_out_grid), _ptr(input), _ptr(grid), _ptr(grad_output), _ptr(offset), None,
+                        _ptr(grad_grid), _ptr(grad_grad_out)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=bool(want_grad_input), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=6)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -836,13 +935,12 @@ def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, gra
                             _one(grad_out_ggout, shape[0]), offset, padding_mode, align_corners, kernel, multicell, ctx)
         return gI, ggO.sum(0, keepdim=True)
     _offset_ok(offset, shape[0], input.device)
-    grad_input = torch.empty_like(input)
     grad_grad_out = torch.empty_like(grad_output)
-    _call("bbb_fused", dim,
-          [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(grad_out_ggout),
-           _ptr(offset), _ptr(grad_input), _ptr(grad_grad_out)],
-          shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
-          want_grad_input=True, go_ns=0, ho_ns=0, grad_output=grad_output, sum_n=True)
+    grad_input = _call("bbb_fused", dim,
+                       [_ptr(input), _ptr(grid), _ptr(grad_output), _ptr(grad_out_grid), _ptr(grad_out_ggrid), _ptr(grad_out_ggout),
+                        _ptr(offset), None, _ptr(grad_grad_out)],
+                       shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
+                       want_grad_input=True, go_ns=0, ho_ns=0, grad_output=grad_output, sum_n=True, gi_index=7)
     return grad_input, grad_grad_out
 
 

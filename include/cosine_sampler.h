@@ -40,8 +40,10 @@
  *     element size.  The kernels use 8- and 16-byte accesses on them; a violation returns CS_ERR_INVALID.
  *   - Return value: 0 on success, a negative CS_ERR_* for argument errors, or a positive
  *     hipError_t from the launch.  cs_error_string() describes either.
- *   - Thread-safe and re-entrant: the library keeps no mutable global state (the one exception is
- *     the process-wide testing knob cs_debug_force_path).
+ *   - Thread-safe and re-entrant: the library keeps no mutable global state.  (The two testing knobs at the end of
+ *     this header, cs_debug_force_path and cs_debug_coherent_tuning, are inert unless the process was started with
+ *     COSINESAMPLER_DEBUG=1 in its environment -- read once, when the library is first used -- and the switches of the
+ *     latter that make results wrong exist only in libraries built with -DCS_COH_DEBUG.)
  */
 #ifndef COSINE_SAMPLER_H
 #define COSINE_SAMPLER_H
@@ -53,7 +55,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 12
+#define CS_ABI_VERSION 13
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -107,6 +109,9 @@ enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD =
 #define CS_STAGE_NO_GRAD_INPUT 0x10
 /* OR-ed into the stage id: the call will carry CS_POINTS_COHERENT (no plan; one channels-last accumulator of scratch) */
 #define CS_STAGE_POINTS_COHERENT 0x20
+/* OR-ed into the stage id: the call will carry cs_cotangent_layout.accumulate_grad_input (the accumulator is the
+ * caller's: no scratch accumulator) */
+#define CS_STAGE_ACCUMULATE 0x40
 
 /* How the channel-major cotangents of a backward stage lie in memory.  The reference demands contiguous
  * (N,C,[Do,]Ho,Wo) tensors (CHECK_CONTIGUOUS, 2d.cpp:5), so PIXEL-style callers, which sum the sampled features
@@ -133,7 +138,31 @@ typedef struct cs_cotangent_layout {
      * (C*P).  Larger when grad_grad_out is a channel range of a wider (N, C_total, P) tensor -- how tables with more channels
      * than the fast paths hold are run as channel groups without gathering the groups' results afterwards. */
     int64_t grad_grad_out_stride_n;
+    /* Non-zero (CS_ACC_NCHW or CS_ACC_CHANNELS_LAST, what cs_accumulator_kind returned for this problem): `grad_input`
+     * is not a result to be defined but the step's ACCUMULATOR -- cs_accumulator_bytes bytes that the caller zeroed
+     * before the first stage of the step -- and the stage ADDS its input-shaped gradient to it: no clear, no layout
+     * conversion.  A training step wants the SUM of the gradients its backward stages produce (the autograd engine adds
+     * them up into cells.grad; a multi-GPU step all-reduces that sum once): with the stages adding into one
+     * buffer a step pays one clear and one conversion (cs_accumulator_finish) instead of one per stage and no adding
+     * passes.  Replaces the zeros_like + per-stage result of 2d.cpp:75, :99, :119.  A stage whose path keeps its sums in
+     * the other layout returns CS_ERR_UNSUPPORTED (nothing has been written: the caller runs it without the flag and adds). */
+    int32_t accumulate_grad_input;
+    int32_t reserved_;
 } cs_cotangent_layout;
+
+/* ---- the step accumulator (not in the reference) ---------------------------------------------------------------------
+ * cs_accumulator_kind: in which layout the backward stages of this problem can ADD into a caller-held accumulator --
+ *   CS_ACC_NONE           not at all on this path (3D fast paths, channel counts beyond the fast path, ...)
+ *   CS_ACC_NCHW           the caller's own (N,C,[D,]H,W) layout: the accumulator can be the final tensor itself
+ *   CS_ACC_CHANNELS_LAST  a padded channels-last image (the coherent-points kernels, CS_POINTS_COHERENT in `kernel`)
+ * `kernel` = the kernel argument of the stage calls, flags included.  cs_accumulator_bytes: its size.
+ * cs_accumulator_finish: the accumulated sum in the caller's layout, `grad_input` (N,C,[D,]H,W); for CS_ACC_NCHW a copy
+ * unless acc == grad_input.  Enqueues on `stream` like everything else. */
+enum { CS_ACC_NONE = 0, CS_ACC_NCHW = 1, CS_ACC_CHANNELS_LAST = 2 };
+int cs_accumulator_kind(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int kernel);
+size_t cs_accumulator_bytes(int dim, int kind, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W);
+int cs_accumulator_finish(int dim, int kind, const float *acc, float *grad_input, int64_t N, int64_t C, int64_t D,
+                          int64_t H, int64_t W, void *stream);
 
 int cs_abi_version(void);
 const char *cs_error_string(int code);
@@ -210,15 +239,19 @@ int cs_points_tile_changes_sampled(int dim, const float *points, uint32_t *count
                                    void *stream);
 /* Tuning / experiments on the coherent kernels: samples_per_wave (a multiple of 64; 0 keeps the value) and ablation_bits,
  * which switch parts of the kernels OFF to see what each costs (results are then wrong): 1 no scatter-reduce, 2 no window
- * flush, 4 no products / outputs; 0 = the product.  Process-wide. */
-void cs_debug_coherent_tuning(int samples_per_wave, int ablation_bits);
+ * flush, 4 no products / outputs; 0 = the product.  Process-wide.  INERT unless COSINESAMPLER_DEBUG=1 was in the
+ * environment when the library was first used, and the ablation bits only exist in a library built with -DCS_COH_DEBUG
+ * (tools/ab.sh): no call can make the shipped library compute wrong results.  Returns 1 if the call took effect. */
+int cs_debug_coherent_tuning(int samples_per_wave, int ablation_bits);
 
 /* Testing knob: 0 = choose the path from the shapes (default), 1 = always the direct (atomics)
  * kernels, 2 = the fast paths wherever they are implemented, whatever the size, 3 = as 2 but crowded tables
  * go through the tile walkers, not the wave-per-cell kernel, 4 = as 2 without the re-use of the sorted grad_output
  * copy between the stages of a step, 5 = as 0 but CS_POINTS_COHERENT is ignored (A/B of the hint), 6 = as 2 but 3D tables
- * are packed by the two-reads kernel instead of the column-wise one (A/B of cs_pack_input).  Process-wide. */
-void cs_debug_force_path(int mode);
+ * are packed by the two-reads kernel instead of the column-wise one (A/B of cs_pack_input).  Every mode computes the
+ * same results.  Process-wide; INERT unless COSINESAMPLER_DEBUG=1 was in the environment when the library was first
+ * used (the test suite sets it).  Returns 1 if the call took effect. */
+int cs_debug_force_path(int mode);
 
 /* ---- 2D -------------------------------------------------------------------------------- */
 

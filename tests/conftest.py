@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library's testing knobs (cs_debug_force_path: which path a problem takes) act only in a process that asks for
+# them before the library is first used (include/cosine_sampler.h); the product default is inert
+os.environ.setdefault("COSINESAMPLER_DEBUG", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

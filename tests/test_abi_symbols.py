@@ -75,6 +75,20 @@ def test_loader_binds_and_reports_errors_without_gpu():
         16 * 8 * 256 * 256 * 4 + lib.cs2d_plan_bytes(16, 5, 256, 256, 1 << 20) + (16 << 20) * 48)
     assert lib.cs_workspace_bytes(2, 1, 16, 33, 1, 256, 256, 1 << 20, 0, 0, 0) == 0     # beyond 32 channels: direct kernels
     assert lib.cs_workspace_bytes(2, 1, 1, 16, 1, 32, 32, 1024, 0, 0, 0) == 0
+    # the step accumulator (cs_cotangent_layout.accumulate_grad_input): which layout the stages of a problem add in, its
+    # size, and the scratch a coherent stage no longer needs when the accumulator is the caller's
+    assert lib.cs_accumulator_kind(2, 16, 16, 1, 256, 256, 1 << 20, 0) == _lib.ACC_NCHW
+    assert lib.cs_accumulator_kind(2, 16, 16, 1, 256, 256, 1 << 20, _lib.POINTS_COHERENT) == _lib.ACC_CHANNELS_LAST
+    assert lib.cs_accumulator_kind(2, 16, 16, 1, 256, 256, 1 << 20, 0x100) == _lib.ACC_NONE       # '+mixed' can leave the fast path
+    assert lib.cs_accumulator_kind(2, 16, 64, 1, 256, 256, 1 << 20, 0) == _lib.ACC_NONE          # beyond 32 channels
+    assert lib.cs_accumulator_kind(3, 8, 8, 128, 128, 128, 1 << 19, 0) == _lib.ACC_NONE
+    assert lib.cs_accumulator_bytes(2, _lib.ACC_NCHW, 16, 5, 1, 256, 256) == 16 * 5 * 256 * 256 * 4
+    assert lib.cs_accumulator_bytes(2, _lib.ACC_CHANNELS_LAST, 16, 5, 1, 256, 256) == 16 * 8 * 256 * 256 * 4
+    assert lib.cs_workspace_bytes(2, 1 | 0x20, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == T2
+    assert lib.cs_workspace_bytes(2, 1 | 0x20 | 0x40, 16, 16, 1, 256, 256, 1 << 20, 1, 0, 0) == 0
+    bad = _lib.CotangentLayout(16, 16, 0, 0, 0, 9, 0)
+    rc = lib.cs2d_backward(None, None, None, None, None, None, 1, 1, 4, 4, 8, 0, 1, 0, 1, bad, None, None, None, 0, None)
+    assert rc == -1
     # argument validation happens before any device work: callable without a GPU
     rc = lib.cs2d_forward(None, None, None, None, 1, 1, 4, 4, 8, 7, 1, 0, 1, None, None, None, 0, None)
     assert rc == -1  # padding_mode 7 is not a mode
@@ -88,6 +102,24 @@ def test_loader_binds_and_reports_errors_without_gpu():
     # zero-sized problems are a no-op, null pointers and all (empty tensors come with null data pointers)
     rc = lib.cs2d_backward(None, None, None, None, None, None, 0, 1, 4, 4, 8, 0, 1, 0, 1, None, None, None, None, 0, None)
     assert rc == 0
+
+
+def test_debug_knobs_are_inert_without_the_environment_variable():
+    """include/cosine_sampler.h: 'no mutable global state' -- cs_debug_* act only in a process started with
+    COSINESAMPLER_DEBUG=1 (the test suite is one: conftest.py); a child process without it gets 0 back from both"""
+    import subprocess
+    import sys
+    code = ("import ctypes,sys; lib=ctypes.CDLL(sys.argv[1]); lib.cs_debug_force_path.restype=ctypes.c_int; "
+            "lib.cs_debug_coherent_tuning.restype=ctypes.c_int; "
+            "print(lib.cs_debug_force_path(2), lib.cs_debug_coherent_tuning(128, 7))")
+    env = dict(os.environ)
+    env.pop("COSINESAMPLER_DEBUG", None)
+    out = subprocess.run([sys.executable, "-c", code, build.LIB], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["0", "0"]
+    env["COSINESAMPLER_DEBUG"] = "1"
+    out = subprocess.run([sys.executable, "-c", code, build.LIB], env=env, capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ["1", "1"]
 
 
 def test_code_object_is_gfx950():
