@@ -348,7 +348,12 @@ class _SamplerBackwardBackward(Function):
         # '+mixed' kernels also return the gradient w.r.t. grid here (u_xxx, u_xxy): the reference has none
         # (modules_2d.py:111).  Terms through gOutInput are not propagated, as everywhere at this level.
         gGrid3 = None
-        if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and not cfg.sum_n and _engine_wants(ctx, 1):
-            gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), _f32(gOut), _f32(gOutGrid), hG, _f32(hO), ctx.offset, cfg.pad,
+        if (cfg.kernel & ops.EXACT_MIXED) and gOutGrid is not None and _engine_wants(ctx, 1):
+            gO3, hO3 = _f32(gOut), _f32(hO)
+            if cfg.sum_n:      # the summed op: one cotangent for every table, the (1,..) grid's gradient summed over n by ops.bbb_grid
+                N = input.shape[0]
+                gO3 = gO3.expand((N,) + tuple(gO3.shape[1:]))
+                hO3 = None if hO3 is None else hO3.expand((N,) + tuple(hO3.shape[1:]))
+            gGrid3 = _as(ops.bbb_grid(_f32(input), _f32(grid), gO3, _f32(gOutGrid), hG, hO3, ctx.offset, cfg.pad,
                                       cfg.align_corners, cfg.kernel, cfg.multicell), grid)
         return _as(gInput, input), gGrid3, _as(ggOut, gOut), None, None, None, None, None, None

@@ -159,10 +159,10 @@ class _Held(object):
 class _PlanEntry(object):
     """A built point plan: its buffer, the grid it was made from (held, so that an equal address means the same memory),
     the configuration it was built for, and whose cell-sorted grad_output copy it currently holds."""
-    __slots__ = ("buf", "of", "cfg", "sorted_go")
+    __slots__ = ("buf", "of", "off", "cfg", "sorted_go")
 
-    def __init__(self, buf, of, cfg):
-        self.buf, self.of, self.cfg, self.sorted_go = buf, of, cfg, None
+    def __init__(self, buf, of, off, cfg):
+        self.buf, self.of, self.off, self.cfg, self.sorted_go = buf, of, off, cfg, None
 
 
 # Plans that outlive a step.  The plan is a function of the grid alone (SURVEY 7: "cached per grid"): a caller that hands the
@@ -301,12 +301,14 @@ class StepContext(object):
 
     def plan(self, lib, grid, offset, dim, shape, P, padding_mode, align_corners, multicell, stream):
         bc = grid.shape[0] == 1 and shape[0] > 1
-        cfg = (offset.data_ptr(),) + tuple(shape) + (int(padding_mode), bool(align_corners), bool(multicell), _force_epoch)
+        # (the plan bins samples by the SHIFTED point: the offsets are part of its identity, held and version-checked like
+        # the grid -- an address alone could be a freed tensor's, re-used, or the same tensor updated in place)
+        cfg = tuple(shape) + (int(padding_mode), bool(align_corners), bool(multicell), _force_epoch)
         pe = self._pe
-        if pe is None or not pe.of.same(grid) or pe.cfg != cfg:
+        if pe is None or not pe.of.same(grid) or not pe.off.same(offset) or pe.cfg != cfg:
             pe = None
             for i, e in enumerate(_plan_cache):              # a plan of this very grid from an earlier step
-                if e.cfg == cfg and e.of.same(grid):
+                if e.cfg == cfg and e.of.same(grid) and e.off.same(offset):
                     pe = e
                     pe.sorted_go = None      # ... but never that step's sorted grad_output copy: a new step, new cotangents
                     _plan_cache.insert(0, _plan_cache.pop(i))
@@ -321,7 +323,7 @@ class StepContext(object):
                     grid.data_ptr(), offset.data_ptr(), buf.data_ptr(), nbytes, *sizes, int(padding_mode),
                     int(bool(align_corners)), int(bool(multicell)), _lib.GRID_BROADCAST if bc else 0, stream),
                     "cs%dd_plan_build" % dim)
-            pe = _PlanEntry(buf, _Held(grid), cfg)
+            pe = _PlanEntry(buf, _Held(grid), _Held(offset), cfg)
             if _plan_cache_size and buf is not None:
                 _plan_cache.insert(0, pe)
                 del _plan_cache[_plan_cache_size:]

@@ -38,6 +38,32 @@
 
 #define CS_PI_F 3.141592654f /* CUDART_PI_F */
 
+/* The input-shaped gradients are sums of many per-sample terms per node (64 at BASELINE configs[1], 1600 at the
+ * reference's own test shapes, test/test_2d.py:26-38).  The reference adds them with fp32 atomics in arrival order
+ * (2d.cu:469-472); this restatement adds them serially in fp32, p by p -- a third, equally arbitrary order.  Built with
+ * -DCS_ORACLE_ACC_DOUBLE (make dacc: _build/libcs_oracle_dacc.so) the TERMS are still the fp32 products of the reference
+ * but their sum is kept in double and rounded once, so that a comparison of a crowded table's gradient measures the
+ * kernel under test and not this checker's own serial rounding. */
+#include <stdlib.h>
+#ifdef CS_ORACLE_ACC_DOUBLE
+typedef double acc_t;
+static acc_t *acc_open(float *out, size_t count) { return out ? (acc_t *)calloc(count ? count : 1, sizeof(acc_t)) : NULL; }
+static int acc_close(acc_t *a, float *out, size_t count) {
+    if (!out) return 0;
+    if (!a) return 1;
+    for (size_t i = 0; i < count; ++i) out[i] = (float)a[i];
+    free(a);
+    return 0;
+}
+#else
+typedef float acc_t;
+static acc_t *acc_open(float *out, size_t count) {
+    if (out) memset(out, 0, sizeof(float) * count); /* zeros_like, 2d.cpp:75, :99, :119 */
+    return out;
+}
+static int acc_close(acc_t *a, float *out, size_t count) { (void)a; (void)out; (void)count; return 0; }
+#endif
+
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 }; /* mod2d.py:4-10 */
 enum { CS_K_COSINE = 0, CS_K_LINEAR = 1, CS_K_SMOOTHSTEP = 2 };        /* mod2d.py:12-18 */
 
@@ -166,7 +192,9 @@ int cs2d_backward_cpu(const float *gOut, const float *input, const float *grid, 
                       float *grad_input, float *grad_grid,
                       int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                       int pad, int align_corners, int kernel, int multicell) {
-    if (grad_input) memset(grad_input, 0, sizeof(float) * (size_t)(N * C * H * W));
+    const size_t acc_count = (size_t)(N * C * H * W);
+    acc_t *accum = acc_open(grad_input, acc_count);
+    if (grad_input && !accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -186,7 +214,7 @@ int cs2d_backward_cpu(const float *gOut, const float *input, const float *grid, 
                 const float *in = input + (n * C + c) * H * W;
                 float go = gOut[(n * C + c) * P + p];
                 if (grad_input) { /* safe_add_2d x4, 2d.cu:469-472 */
-                    float *gi = grad_input + (n * C + c) * H * W;
+                    acc_t *gi = accum + (n * C + c) * H * W;
                     if (inb2(yt, xl, H, W)) gi[yt * W + xl] += nw * go;
                     if (inb2(yt, xr, H, W)) gi[yt * W + xr] += ne * go;
                     if (inb2(yb, xl, H, W)) gi[yb * W + xl] += sw * go;
@@ -202,7 +230,7 @@ int cs2d_backward_cpu(const float *gOut, const float *input, const float *grid, 
             grad_grid[(n * P + p) * 2 + 1] = my * giy * dky;
         }
     }
-    return 0;
+    return acc_close(accum, grad_input, acc_count);
 }
 
 /* K3 -- cosine_sampler_backward_backward_kernel, 2d.cu:509-717.
@@ -214,7 +242,9 @@ int cs2d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
                                float *gInput, float *gGrid, float *ggOut,
                                int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                                int pad, int align_corners, int kernel, int multicell) {
-    memset(gInput, 0, sizeof(float) * (size_t)(N * C * H * W)); /* 2d.cpp:99 */
+    const size_t acc_count = (size_t)(N * C * H * W);
+    acc_t *accum = acc_open(gInput, acc_count); /* 2d.cpp:99 */
+    if (!accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -251,7 +281,7 @@ int cs2d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
             for (int64_t c = 0; c < C; ++c) {
                 const float *in = input + (n * C + c) * H * W;
                 const float *goi = gOutInput ? gOutInput + (n * C + c) * H * W : NULL;
-                float *gi = gInput + (n * C + c) * H * W;
+                acc_t *gi = accum + (n * C + c) * H * W;
                 float go = gOut[(n * C + c) * P + p];
                 float acc = 0.0f; /* the reference accumulates this through atomics on a zeroed ggOut */
                 for (int a = 0; a < 4; ++a) {
@@ -272,7 +302,7 @@ int cs2d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
             gGrid[(n * P + p) * 2 + 1] = s2y;
         }
     }
-    return 0;
+    return acc_close(accum, gInput, acc_count);
 }
 
 /* K4 -- cosine_sampler_backward_backward_backward_kernel, 2d.cu:722-891.
@@ -283,7 +313,9 @@ int cs2d_backward_backward_backward_cpu(const float *input, const float *grid, c
                                         float *gInput, float *ggOut,
                                         int64_t N, int64_t C, int64_t H, int64_t W, int64_t P,
                                         int pad, int align_corners, int kernel, int multicell) {
-    memset(gInput, 0, sizeof(float) * (size_t)(N * C * H * W)); /* 2d.cpp:119 */
+    const size_t acc_count = (size_t)(N * C * H * W);
+    acc_t *accum = acc_open(gInput, acc_count); /* 2d.cpp:119 */
+    if (!accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -312,7 +344,7 @@ int cs2d_backward_backward_backward_cpu(const float *input, const float *grid, c
             float hgx = gOutgGrid[(n * P + p) * 2 + 0], hgy = gOutgGrid[(n * P + p) * 2 + 1];
             for (int64_t c = 0; c < C; ++c) {
                 const float *in = input + (n * C + c) * H * W;
-                float *gi = gInput + (n * C + c) * H * W;
+                acc_t *gi = accum + (n * C + c) * H * W;
                 float go = gOut[(n * C + c) * P + p];
                 float acc = 0.0f;
                 for (int a = 0; a < 4; ++a) {
@@ -327,7 +359,7 @@ int cs2d_backward_backward_backward_cpu(const float *input, const float *grid, c
             }
         }
     }
-    return 0;
+    return acc_close(accum, gInput, acc_count);
 }
 
 /* =================================================================== */
@@ -374,7 +406,9 @@ int cs3d_backward_cpu(const float *gOut, const float *input, const float *grid, 
                       float *grad_input, float *grad_grid,
                       int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                       int pad, int align_corners, int kernel, int multicell) {
-    if (grad_input) memset(grad_input, 0, sizeof(float) * (size_t)(N * C * D * H * W));
+    const size_t acc_count = (size_t)(N * C * D * H * W);
+    acc_t *accum = acc_open(grad_input, acc_count);
+    if (grad_input && !accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -394,7 +428,7 @@ int cs3d_backward_cpu(const float *gOut, const float *input, const float *grid, 
             float sx = 0.0f, sy = 0.0f, sz = 0.0f;
             for (int64_t c = 0; c < C; ++c) {
                 const float *in = input + (n * C + c) * D * H * W;
-                float *gi = grad_input ? grad_input + (n * C + c) * D * H * W : NULL;
+                acc_t *gi = grad_input ? accum + (n * C + c) * D * H * W : NULL;
                 float go = gOut[(n * C + c) * P + p];
                 for (int a = 0; a < 8; ++a) {
                     int px = a & 1, py = (a >> 1) & 1, pz = (a >> 2) & 1;
@@ -416,7 +450,7 @@ int cs3d_backward_cpu(const float *gOut, const float *input, const float *grid, 
             grad_grid[(n * P + p) * 3 + 2] = mz * sz * dkz;
         }
     }
-    return 0;
+    return acc_close(accum, grad_input, acc_count);
 }
 
 /* K7 -- 3d.cu:587-870.  Has the mixed second derivatives (3d.cu:758-771) and
@@ -426,7 +460,9 @@ int cs3d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
                                float *gInput, float *gGrid, float *ggOut,
                                int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                                int pad, int align_corners, int kernel, int multicell) {
-    memset(gInput, 0, sizeof(float) * (size_t)(N * C * D * H * W));
+    const size_t acc_count = (size_t)(N * C * D * H * W);
+    acc_t *accum = acc_open(gInput, acc_count);
+    if (!accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -473,7 +509,7 @@ int cs3d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
             for (int64_t c = 0; c < C; ++c) {
                 const float *in = input + (n * C + c) * D * H * W;
                 const float *goi = gOutInput ? gOutInput + (n * C + c) * D * H * W : NULL;
-                float *gi = gInput + (n * C + c) * D * H * W;
+                acc_t *gi = accum + (n * C + c) * D * H * W;
                 float go = gOut[(n * C + c) * P + p];
                 float acc = 0.0f;
                 for (int a = 0; a < 8; ++a) {
@@ -501,7 +537,7 @@ int cs3d_backward_backward_cpu(const float *gOutInput, const float *gOutGrid,
             gGrid[(n * P + p) * 3 + 2] = s2z;
         }
     }
-    return 0;
+    return acc_close(accum, gInput, acc_count);
 }
 
 /* K8 -- 3d.cu:875-1071.  Back to the t = right - i convention with k(t) as
@@ -511,7 +547,9 @@ int cs3d_backward_backward_backward_cpu(const float *input, const float *grid, c
                                         float *gInput, float *ggOut,
                                         int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                                         int pad, int align_corners, int kernel, int multicell) {
-    memset(gInput, 0, sizeof(float) * (size_t)(N * C * D * H * W));
+    const size_t acc_count = (size_t)(N * C * D * H * W);
+    acc_t *accum = acc_open(gInput, acc_count);
+    if (!accum) return 1;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         for (int64_t p = 0; p < P; ++p) {
@@ -541,7 +579,7 @@ int cs3d_backward_backward_backward_cpu(const float *input, const float *grid, c
             const float *hg = gOutgGrid + (n * P + p) * 3;
             for (int64_t c = 0; c < C; ++c) {
                 const float *in = input + (n * C + c) * D * H * W;
-                float *gi = gInput + (n * C + c) * D * H * W;
+                acc_t *gi = accum + (n * C + c) * D * H * W;
                 float go = gOut[(n * C + c) * P + p];
                 float acc = 0.0f;
                 for (int a = 0; a < 8; ++a) {
@@ -556,5 +594,5 @@ int cs3d_backward_backward_backward_cpu(const float *input, const float *grid, c
             }
         }
     }
-    return 0;
+    return acc_close(accum, gInput, acc_count);
 }

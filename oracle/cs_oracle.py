@@ -16,7 +16,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcs_oracle.so")
+_SO_DACC = os.path.join(_HERE, "_build", "libcs_oracle_dacc.so")
 _lib = None
+_lib_dacc = None
+# True: the input-shaped gradients come from the build that sums them in double (make dacc) -- for comparisons on crowded
+# tables, where the checker's own serial fp32 rounding would otherwise be the tolerance; set through double_accumulation()
+_use_dacc = False
 
 _f = ctypes.POINTER(ctypes.c_float)
 _i64 = ctypes.c_int64
@@ -24,23 +29,41 @@ _int = ctypes.c_int
 
 
 def build(force=False):
-    """Compile the C restatement with gcc (seconds)."""
+    """Compile the C restatement with gcc (seconds): the plain build and the double-accumulating one."""
     src = os.path.join(_HERE, "cs_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "all"])
+    for so, target in ((_SO, "all"), (_SO_DACC, "dacc")):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", target])
     return _SO
 
 
+_NAMES = ("cs2d_forward_cpu", "cs2d_backward_cpu", "cs2d_backward_backward_cpu",
+          "cs2d_backward_backward_backward_cpu", "cs3d_forward_cpu", "cs3d_backward_cpu",
+          "cs3d_backward_backward_cpu", "cs3d_backward_backward_backward_cpu")
+
+
 def lib():
-    global _lib
+    global _lib, _lib_dacc
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_SO)
-        for name in ("cs2d_forward_cpu", "cs2d_backward_cpu", "cs2d_backward_backward_cpu",
-                     "cs2d_backward_backward_backward_cpu", "cs3d_forward_cpu", "cs3d_backward_cpu",
-                     "cs3d_backward_backward_cpu", "cs3d_backward_backward_backward_cpu"):
-            getattr(_lib, name).restype = _int
-    return _lib
+        _lib, _lib_dacc = ctypes.CDLL(_SO), ctypes.CDLL(_SO_DACC)
+        for l in (_lib, _lib_dacc):
+            for name in _NAMES:
+                getattr(l, name).restype = _int
+    return _lib_dacc if _use_dacc else _lib
+
+
+class double_accumulation(object):
+    """with cs_oracle.double_accumulation(): ... -- the input-shaped gradients of the calls inside are summed in double
+    (same fp32 terms, one rounding at the end): the checker for crowded tables."""
+
+    def __enter__(self):
+        global _use_dacc
+        self._was, _use_dacc = _use_dacc, True
+
+    def __exit__(self, *exc):
+        global _use_dacc
+        _use_dacc = self._was
 
 
 def _p(t):

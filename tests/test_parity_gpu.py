@@ -1156,14 +1156,15 @@ def test_rccl_path_runs_on_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["ms_per_step_no_reduce"] > 0 and "allreduce_ms" in line and "RCCL" in line["reduce"]
-    assert line["reduce_schedule"] == "per_stage"
-    # the other schedule (one all-reduce per step on the accumulated gradient)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-alone", "--reduce", "once", "--points", "131072",
+    # the default schedule: the stages add into one step accumulator, ONE all-reduce per step on its sum
+    assert line["reduce_schedule"] == "once" and "ONE RCCL all-reduce" in line["reduce"]
+    # the other schedule: the three gradients kept apart, each reduced asynchronously as soon as its stage is enqueued
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-alone", "--reduce", "per_stage", "--points", "131072",
                         "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-helmholtz"], capture_output=True,
                        text=True, timeout=300, env=dict(env, MASTER_PORT="29535"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["reduce_schedule"] == "once" and "ONE RCCL all-reduce" in line["reduce"] and line["value"] > 0
+    assert line["reduce_schedule"] == "per_stage" and "3 RCCL all-reduces" in line["reduce"] and line["value"] > 0
 
 
 def test_integration_stub_from_the_document():
