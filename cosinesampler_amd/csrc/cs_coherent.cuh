@@ -50,7 +50,12 @@ enum { FWD = 0, BWD = 1, BB = 2, BBB = 3 };
 #ifndef CS_COH_DEPTH_BWD
 #define CS_COH_DEPTH_BWD 2
 #endif
-__host__ __device__ constexpr int depth(int mode) { return mode == FWD ? 4 : mode == BWD ? CS_COH_DEPTH_BWD : 2; }
+#ifndef CS_COH_DEPTH_BB
+#define CS_COH_DEPTH_BB 2
+#endif
+__host__ __device__ constexpr int depth(int mode) {
+    return mode == FWD ? 4 : mode == BWD ? CS_COH_DEPTH_BWD : mode == BB ? CS_COH_DEPTH_BB : 2;
+}
 
 template <int C>
 struct Lay {
@@ -58,6 +63,7 @@ struct Lay {
     static constexpr int NH = C > 16 ? C / 16 : 1;     // 16-channel halves (one accumulator tile each)
     static constexpr int PT = 66;                      // pitch of the channel-major cotangent rows [C][PT]: the matrix
                                                        // core's B reads (16 channels x 2 samples per half wave) hit 32 banks
+    static constexpr int PTH = 34;                     // ... when the rows hold half a batch (half_batch()): same banks
 #ifndef CS_COH_ROW_PAD
 #define CS_COH_ROW_PAD 4
 #endif
@@ -71,11 +77,27 @@ struct Lay {
     static constexpr int WINA = WNY * ROWA;            // matrix core's result (half a wave) land 16 banks apart
 };
 
+// The first backward stages the scatter-reduce's operands HALF a batch at a time (32 samples: lanes 0..31, then lanes
+// 32..63 through the same LDS rows).  It is the stage with the fewest bytes per sample to hide behind and the one whose
+// registers (<= 128) admit four waves per SIMD; the whole-batch operands (8.4 KiB of a wave's 13.7) kept it at 2.75, and
+// capping the waves per CU showed these kernels follow their occupancy (8 instead of 11 waves per CU: +15 %).  Halved,
+// a wave takes 9.6 KiB -> 16 per CU.  The second / third backward hold 140-168 registers (3 waves per SIMD at best) and
+// keep whole batches: they would pay the second round of stores for one more wave per CU.
+#ifdef CS_COH_NO_HALF          // A/B builds (tools/ab.sh)
+__host__ __device__ constexpr bool half_batch(int) { return false; }
+#else
+#ifdef CS_COH_HALF_BB
+__host__ __device__ constexpr bool half_batch(int mode) { return mode == BWD || mode == BB; }
+#else
+__host__ __device__ constexpr bool half_batch(int mode) { return mode == BWD; }
+#endif
+#endif
 // per wave (floats): cotangent rows GT, coefficient blocks KA, the table window TW, the accumulator window AW -- in
 // this order: the reads of a run's last, partly masked group of four may run past GT / KA into what follows
 template <int C>
 __host__ __device__ constexpr int wave_floats(int mode) {
-    return mode == FWD ? Lay<C>::WIN : C * Lay<C>::PT + 64 * KP + Lay<C>::WIN + Lay<C>::WINA;
+    return mode == FWD ? Lay<C>::WIN
+                       : C * (half_batch(mode) ? Lay<C>::PTH : Lay<C>::PT) + (half_batch(mode) ? 32 : 64) * KP + Lay<C>::WIN + Lay<C>::WINA;
 }
 
 // LDS traffic of one wave is in program order; this only keeps the compiler from moving accesses of OTHER lanes' data
@@ -210,7 +232,7 @@ struct Windows {
 // S[4 r + v][j] = block row r, column v -- a k-ordered fma chain in exact fp32.  Groups of four samples are counted from
 // the run's first sample; the lanes of the last group that belong to the next run are masked on both operands (their
 // reads may run past the arrays into the wave's own LDS: any value will do).  Then into AW at block column bx.
-template <int C>
+template <int C, int PT>
 __device__ __forceinline__ void scatter_run(const float *KA, const float *GT, float *aw, int js, int len, int bx) {
     using L = Lay<C>;
     constexpr int NH = L::NH;
@@ -225,7 +247,7 @@ __device__ __forceinline__ void scatter_run(const float *KA, const float *GT, fl
 #pragma unroll
         for (int v = 0; v < 4; ++v) old[h][v] = wp[16 * h + v * C];
     const float *ka = KA + (js + k) * KP + m;
-    const float *gp = GT + cc * L::PT + js + k;
+    const float *gp = GT + cc * PT + js + k;
 #pragma unroll
     for (int u0 = 0; u0 < 16; u0 += 4) {
         if (4 * u0 >= len) break;                            // wave-uniform
@@ -234,7 +256,7 @@ __device__ __forceinline__ void scatter_run(const float *KA, const float *GT, fl
         for (int u = 0; u < 4; ++u) {                        // every operand of four instructions before the first
             a[u] = ka[(u0 + u) * 4 * KP];
 #pragma unroll
-            for (int h = 0; h < NH; ++h) b[u][h] = gp[16 * h * L::PT + (u0 + u) * 4];
+            for (int h = 0; h < NH; ++h) b[u][h] = gp[16 * h * PT + (u0 + u) * 4];
         }
         if (4 * (u0 + 4) <= len) {                           // sixteen samples of the run: nothing to mask
 #pragma unroll
@@ -271,37 +293,108 @@ template <typename T>
 __device__ __forceinline__ T *at(T *ubase, uint32_t byteoff) {
     return reinterpret_cast<T *>(reinterpret_cast<char *>(ubase) + byteoff);
 }
+// The channel-major streams go through BUFFER instructions: a 128-bit descriptor (scalar registers) of the wave's first
+// sample in channel row 16 g; row c of the group = a scalar byte offset (c mod 4) * P * sizeof(T) -- four scalar registers
+// worked out once, shared by every stream of the kernel -- plus the lane's offset inside the chunk moved by (c / 4) * 4 rows
+// (four vector registers per batch, three adds, shared by the streams as well: all have the row pitch P).  No other address
+// arithmetic is left in the batch loop: the pointer form spent six scalar instructions per row and batch (96 of the ~180
+// scalar instructions of a batch at 16 channels) on 64-bit row bases it could not keep.  (Sixteen scalar row offsets
+// instead of 4 + 4 made the second and third backward spill scalar registers to vector lanes: 100 / 240 v_readlane.)
+// Reach of one descriptor: 15 rows + a chunk, in 32 bits (Launch: supported()).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int RG = 16;                                  // channel rows per descriptor
+constexpr int RQ = 4;                                   // rows per scalar offset set
+struct RowOffs {
+    uint32_t s[RQ];        // (c mod 4) rows, bytes: wave-uniform, loop-invariant
+    uint32_t quad;         // 4 rows, bytes
+    int Cv;                // the caller's channel count (<= the padded count C the kernel is built for)
+    template <typename T>
+    __device__ __forceinline__ void init(int64_t P, int Cv_) {
+        Cv = Cv_;
+        const uint32_t row = (uint32_t)P * (uint32_t)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) s[i] = (uint32_t)i * row;
+        quad = RQ * row;
+    }
+    // The caller's channel count for the per-row tests of the padded case, opaque to the optimiser: left visible, the
+    // sixteen wave-uniform comparisons c < Cv are hoisted out of the batch loop as sixteen 64-bit masks -- thirty-two scalar
+    // registers, which the second and third backward then spill to vector lanes (100 / 240 v_readlane per batch pair).
+    __device__ __forceinline__ int channels() const {
+        int c = Cv;
+        asm volatile("" : "+s"(c));
+        return c;
+    }
+};
+// the lane's byte offset inside the chunk for each of the four row quads of a group
+struct LaneOffs {
+    uint32_t v[RG / RQ];
+    __device__ __forceinline__ void set(uint32_t byteoff, const RowOffs &ro) {
+#pragma unroll
+        for (int q = 0; q < RG / RQ; ++q) v[q] = byteoff + (uint32_t)q * ro.quad;
+    }
+};
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+template <int C, typename T>
+struct Rows {
+    static constexpr int NG = (C + RG - 1) / RG;
+    rsrc_t r[NG];
+    __device__ __forceinline__ void init(const T *row0, int64_t P) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) r[g] = make_rsrc(row0 ? row0 + (int64_t)g * RG * P : nullptr);
+    }
+};
+template <typename T>
+__device__ __forceinline__ T load_elem(rsrc_t r, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 2));        // 2: nontemporal
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 2));
+    }
+}
+// outputs leave nontemporal: the table is read through the windows, nothing here wants to stay in the L2 (forward:
+// 0.300 -> 0.242 ms against write-through stores, the other stages unchanged)
+template <typename T>
+__device__ __forceinline__ void store_elem(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+    const T t = (T)v;
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), r, (int)voff, (int)soff, 2);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), r, (int)voff, (int)soff, 2);
+    }
+}
 // channel c of this lane's sample; channels >= Cv do not exist (C padded up to a supported count)
 template <int C, typename T>
 struct StreamRegs {
     T raw[C];
-    // row0: channel 0 at the first sample of the wave's chunk; rows are P elements apart.  The row bases are worked
-    // out here, one scalar add each: left to itself the compiler keeps all of them in scalar registers across the batch
-    // loop and spills what the loop really needs.
-    __device__ __forceinline__ void issue(const T *row0, uint32_t byteoff, int64_t P, int Cv) {
-        asm volatile("" : "+s"(P));
-        const T *row = row0;
+    // every row is loaded, unconditionally (a load inside a wave-uniform branch is waited for at the join: serialized
+    // round trips); rows the caller does not have -- C padded up to a supported count -- re-read an existing row and are
+    // zeroed in arrived()
+    __device__ __forceinline__ void issue(const Rows<C, T> &rows, const LaneOffs &lo, const RowOffs &ro) {
+        if (ro.Cv == C) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            raw[c] = __builtin_nontemporal_load(at(row, byteoff));
-            if (c + 1 < Cv) row += P;
+            for (int c = 0; c < C; ++c) raw[c] = load_elem<T>(rows.r[c / RG], lo.v[(c % RG) / RQ], ro.s[c % RQ]);
+        } else {
+            const int cv = ro.channels();
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const bool have = c < cv;
+                raw[c] = load_elem<T>(rows.r[have ? c / RG : 0], have ? lo.v[(c % RG) / RQ] : lo.v[0], have ? ro.s[c % RQ] : 0u);
+            }
         }
     }
     // channels past Cv read as zero (wave-uniform: nothing to do when no channel is padded)
-    __device__ __forceinline__ void arrived(int Cv) {
-        if (Cv < C) {
+    __device__ __forceinline__ void arrived(const RowOffs &ro) {
+        if (ro.Cv < C) {
+            const int cv = ro.channels();
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                if (c >= Cv) raw[c] = (T)0.0f;
+                if (c >= cv) raw[c] = (T)0.0f;
         }
     }
     __device__ __forceinline__ float val(int c) const { return (float)raw[c]; }
 };
-// outputs leave nontemporal: the table is read through the windows, nothing here wants to stay in the L2 (forward:
-// 0.300 -> 0.242 ms against write-through stores, the other stages unchanged)
-template <typename T>
-__device__ __forceinline__ void store_out(T *p, float v) { __builtin_nontemporal_store((T)v, p); }
-
 // a sample's coefficients -> its block (the block is zero everywhere else: cleared by the same lane after the batch)
 __device__ __forceinline__ void put_coefs(float *blk, int slot0, const float (&k)[4]) {
     blk[slot0] = k[0];
@@ -309,11 +402,10 @@ __device__ __forceinline__ void put_coefs(float *blk, int slot0, const float (&k
     blk[slot0 + 4] = k[2];
     blk[slot0 + 5] = k[3];
 }
-template <int C, typename R>
-__device__ __forceinline__ void put_rows(float *GT, const R &regs) {
-    const int lane = threadIdx.x & 63;
+template <int C, int PT, typename R>
+__device__ __forceinline__ void put_rows(float *GT, const R &regs, int col) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) GT[c * Lay<C>::PT + lane] = regs.val(c);
+    for (int c = 0; c < C; ++c) GT[c * PT + col] = regs.val(c);
 }
 
 struct Args {
@@ -355,7 +447,10 @@ struct Args {
 // accumulator, products -- adding the per-point results up in registers, and writes them once: the (N,C,P) streams of
 // the plain op, 1 GiB each at BASELINE configs[1], shrink N-fold and the caller's sums over n disappear.
 template <int KERNEL, int CQ, int MODE, bool TWO, bool SCAT, typename ST, bool COMMON = false, bool NSUM = false>
-__global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
+#ifndef CS_COH_BWD_WAVES
+#define CS_COH_BWD_WAVES 4       // waves per SIMD the first backward is compiled for (A/B builds)
+#endif
+__global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : (half_batch(MODE) && SCAT) ? CS_COH_BWD_WAVES : 3) void stage(Args a, Dims d, Flags f_, int chunk, int dbg) {
     Flags f = f_;
 #ifndef CS_COH_DEBUG
     dbg = 0;      // the ablation switches (wrong results by design) exist only in experiment builds (-DCS_COH_DEBUG, tools/ab.sh)
@@ -380,9 +475,12 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
     const int64_t p_begin = wv * chunk;
     if (p_begin >= d.P) return;
     const int count = (int)min((int64_t)chunk, d.P - p_begin);       // samples of this wave
+    constexpr bool HALF = ACC && half_batch(MODE);       // the scatter-reduce's operands go through LDS 32 samples at a time
+    constexpr int PTV = HALF ? L::PTH : L::PT;           // pitch of the cotangent rows
+    constexpr int NB = HALF ? 32 : 64;                   // coefficient blocks
     float *GT = lds + wib * wave_floats<C>(ACC ? MODE : FWD);
-    float *KA = GT + C * L::PT;
-    float *TW = ACC ? KA + 64 * KP : GT;
+    float *KA = GT + C * PTV;
+    float *TW = ACC ? KA + NB * KP : GT;
     float *AW = TW + L::WIN;
     float off = a.offset[n];
     const float *tab_n = a.icl + (int64_t)n * d.vol * C;
@@ -391,9 +489,14 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
     const float *grid_w = a.grid + (d.gpt(n, p_begin)) * 2;
     const float *cg_w = (MODE >= BB && a.cG) ? a.cG + (d.gpt(n, p_begin)) * 2 : nullptr;
     const float *hg_w = (MODE == BBB && a.hG) ? a.hG + (d.gpt(n, p_begin)) * 2 : nullptr;
-    const ST *go_w = IN ? (const ST *)a.gOut + (int64_t)n * d.go_ns + p_begin : nullptr;
-    const ST *ho_w = TWO ? (const ST *)a.hO + (int64_t)n * d.ho_ns + p_begin : nullptr;
-    ST *os_w = OUTS ? (ST *)a.out_stream + (int64_t)n * d.out_ns + p_begin : nullptr;
+    Rows<IN ? C : 1, ST> go_r;
+    Rows<TWO ? C : 1, ST> ho_r;
+    Rows<OUTS ? C : 1, ST> os_r;
+    go_r.init(IN ? (const ST *)a.gOut + (int64_t)n * d.go_ns + p_begin : nullptr, d.P);
+    ho_r.init(TWO ? (const ST *)a.hO + (int64_t)n * d.ho_ns + p_begin : nullptr, d.P);
+    os_r.init(OUTS ? (const ST *)a.out_stream + (int64_t)n * d.out_ns + p_begin : nullptr, d.P);
+    RowOffs ro;
+    ro.init<ST>(d.P, d.C);
     float *og_w = (MODE == BWD || MODE == BB) ? a.out_grid + ((int64_t)n * d.P + p_begin) * 2 : nullptr;
 
     Windows<C, ACC> w;
@@ -401,7 +504,7 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
     w.noflush = (dbg & 2) != 0;
     w.noload = (dbg & 32) != 0;
     if (ACC) {
-        for (int i = lane; i < 64 * KP; i += 64) KA[i] = 0.0f;
+        for (int i = lane; i < NB * KP; i += 64) KA[i] = 0.0f;
     }
     // DEPTH register sets of stream loads, each re-issued for the batch DEPTH ahead as soon as its batch is done with it
     struct Pre {
@@ -415,8 +518,12 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
         s.cg = s.hg = make_float2(0.f, 0.f);
         if (cg_w) s.cg = *at(reinterpret_cast<const float2 *>(cg_w), r * 8u);
         if (hg_w) s.hg = *at(reinterpret_cast<const float2 *>(hg_w), r * 8u);
-        if constexpr (IN) s.sg.issue(go_w, r * (uint32_t)sizeof(ST), d.P, d.C);
-        if constexpr (TWO) s.sh.issue(ho_w, r * (uint32_t)sizeof(ST), d.P, d.C);
+        if constexpr (IN) {
+            LaneOffs lo;
+            lo.set(r * (uint32_t)sizeof(ST), ro);
+            s.sg.issue(go_r, lo, ro);
+            if constexpr (TWO) s.sh.issue(ho_r, lo, ro);
+        }
     };
     // per-point results of one batch; NSUM: summed over the tables before they leave
     struct Res {
@@ -434,13 +541,16 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
         if ((MODE == BWD || MODE == BB) && live)
             *at(reinterpret_cast<float2 *>(og_w), (uint32_t)rel * 8u) = make_float2(r.gx, r.gy);
         if (OUTS && live) {
-            int64_t Pv = d.P;
-            asm volatile("" : "+s"(Pv));
-            ST *row = os_w;
+            LaneOffs lo;
+            lo.set((uint32_t)rel * (uint32_t)sizeof(ST), ro);
+            if (ro.Cv == C) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (c < d.C) store_out(at(row, (uint32_t)rel * (uint32_t)sizeof(ST)), r.O[c]);
-                row += Pv;
+                for (int c = 0; c < C; ++c) store_elem<ST>(os_r.r[c / RG], lo.v[(c % RG) / RQ], ro.s[c % RQ], r.O[c]);
+            } else {
+                const int cv = ro.channels();
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (c < cv) store_elem<ST>(os_r.r[c / RG], lo.v[(c % RG) / RQ], ro.s[c % RQ], r.O[c]);
             }
         }
     };
@@ -449,8 +559,8 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
         const bool live = rel < count;
         Geo g;
         make_geo<KERNEL, ORD>(g, s.xy, off, d, f, live);    // the wait of the batch: loads issued DEPTH batches ago
-        if constexpr (IN) s.sg.arrived(d.C);
-        if constexpr (TWO) s.sh.arrived(d.C);
+        if constexpr (IN) s.sg.arrived(ro);
+        if constexpr (TWO) s.sh.arrived(ro);
         const float2 cgb = s.cg, hgb = s.hg;
 
         // coefficients: kS scatters gOut and weights the table rows of the output stream, kH scatters hO (TWO)
@@ -478,12 +588,14 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
             }
         }
         const bool valid = g.akey != KEY_NONE;
-        float *blk = KA + lane * KP;
+        float *blk = KA + (HALF ? (lane & 31) : lane) * KP;
         const int s0 = g.slot0();
-        if constexpr (ACC && !TWO) {                        // the scatter operands of the whole batch, once
+        const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+        int rhalf = -1;                                     // HALF: whose operands sit in LDS (lanes 32 rhalf .. 32 rhalf + 31)
+        if constexpr (ACC && !TWO && !HALF) {               // the scatter operands of the whole batch, once
             if (!(dbg & 64)) {
                 put_coefs(blk, s0, kS);
-                put_rows<C>(GT, s.sg);
+                put_rows<C, PTV>(GT, s.sg, lane);
             }
         }
         float Y[4] = {0.f, 0.f, 0.f, 0.f};
@@ -506,21 +618,58 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
             if (ACC && !(dbg & 1)) {
 #pragma unroll
                 for (int pass = TWO ? 0 : 1; pass < 2; ++pass) {
-                    if constexpr (TWO) {                    // (hO, D) then (gOut, E) through the same LDS rows
+                    if constexpr (!HALF) {
+                        if constexpr (TWO) {                    // (hO, D) then (gOut, E) through the same LDS rows
+                            wave_sync();
+                            put_coefs(blk, s0, pass ? kS : kH);
+                            if (pass) put_rows<C, PTV>(GT, s.sg, lane);
+                            else put_rows<C, PTV>(GT, s.sh, lane);
+                        }
                         wave_sync();
-                        put_coefs(blk, s0, pass ? kS : kH);
-                        if (pass) put_rows<C>(GT, s.sg);
-                        else put_rows<C>(GT, s.sh);
-                    }
-                    wave_sync();
-                    uint64_t hs = heads & seg;
-                    while (hs) {
-                        const int js = __ffsll((unsigned long long)hs) - 1;
-                        hs &= hs - 1;
-                        const uint64_t later = heads & ~((2ull << js) - 1);
-                        const int je = later ? __ffsll((unsigned long long)later) - 1 : 64;
-                        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)g.akey, js);
-                        scatter_run<C>(KA, GT, w.aw, js, je - js, w.column(key));
+                        uint64_t hs = heads & seg;
+                        while (hs) {
+                            const int js = __ffsll((unsigned long long)hs) - 1;
+                            hs &= hs - 1;
+                            const uint64_t later = heads & ~((2ull << js) - 1);
+                            const int je = later ? __ffsll((unsigned long long)later) - 1 : 64;
+                            const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)g.akey, js);
+                            scatter_run<C, PTV>(KA, GT, w.aw, js, je - js, w.column(key));
+                        }
+                    } else {
+                        // half a batch at a time through the same rows and blocks; a run that crosses the middle of the
+                        // batch is reduced in two parts (lane 32 counts as a head)
+                        const uint64_t hd = heads | (1ull << 32);
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const uint64_t hm = half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                            uint64_t hs = hd & seg & hm;
+                            if (!hs) continue;                      // wave-uniform
+                            wave_sync();
+                            if (rhalf >= 0 && rhalf != half) {          // the other half's blocks go back to zero first: same storage
+                                if ((lane >> 5) == rhalf) put_coefs(blk, s0, zero4);
+                                wave_sync();
+                            }
+                            if ((lane >> 5) == half) {
+                                if constexpr (TWO) {
+                                    put_coefs(blk, s0, pass ? kS : kH);
+                                    if (pass) put_rows<C, PTV>(GT, s.sg, lane & 31);
+                                    else put_rows<C, PTV>(GT, s.sh, lane & 31);
+                                } else {
+                                    put_coefs(blk, s0, kS);
+                                    put_rows<C, PTV>(GT, s.sg, lane & 31);
+                                }
+                            }
+                            rhalf = half;
+                            wave_sync();
+                            while (hs) {
+                                const int js = __ffsll((unsigned long long)hs) - 1;
+                                hs &= hs - 1;
+                                const uint64_t later = hd & ~((2ull << js) - 1);
+                                const int je = later ? __ffsll((unsigned long long)later) - 1 : 64;
+                                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)g.akey, js);
+                                scatter_run<C, PTV>(KA, GT, w.aw, js - 32 * half, je - js, w.column(key));
+                            }
+                        }
                     }
                     w.dirty = true;
                 }
@@ -554,8 +703,7 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : 3) void stage(Args a, D
         }
         if constexpr (ACC) {                                // the blocks go back to zero for the next batch
             wave_sync();
-            const float z[4] = {0.f, 0.f, 0.f, 0.f};
-            put_coefs(blk, s0, z);
+            if (!HALF || (lane >> 5) == rhalf) put_coefs(blk, s0, zero4);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the set is free: its next loads go out, DEPTH batches of work to arrive in (NSUM: the sets are loaded once)

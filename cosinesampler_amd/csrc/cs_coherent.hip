@@ -102,8 +102,10 @@ bool supported_nsum(const Launch &L) {
 }
 
 bool supported(const Launch &L) {
+    // (a stream's buffer descriptor reaches fifteen channel rows and a chunk past the wave's first sample in 32 bits:
+    // beyond P = 2^26 points per table the general path takes over)
     return L.d.size[0] <= MAX_SIZE && L.d.size[1] <= MAX_SIZE && L.d.N <= 65535 && L.d.P > 0 &&
-           (L.d.P + 255) / 256 <= (int64_t)INT32_MAX &&
+           (L.d.P + 255) / 256 <= (int64_t)INT32_MAX && L.d.P <= ((int64_t)1 << 26) &&
            (L.cq == 1 || L.cq == 2 || L.cq == 4 || L.cq == 8);
 }
 

@@ -354,10 +354,11 @@ _FLAGS = EXACT_MIXED | _lib.STREAM_F16 | _lib.STREAM_BF16 | _lib.GRID_BROADCAST 
 call_counts = {}
 
 
-def _count(stage, scattered):
-    c = call_counts.setdefault(stage, [0, 0])
+def _count(stage, scattered, coherent):
+    c = call_counts.setdefault(stage, [0, 0, 0])      # calls, of which scattered, of which on the coherent-points kernels
     c[0] += 1
     c[1] += int(bool(scattered))
+    c[2] += int(bool(coherent))
 
 
 def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multicell, device, ctx=None, input=None,
@@ -437,7 +438,7 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
         return _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel_in, multicell, device, ctx, input, grid,
                      offset, want_grad_input, have_cI, go_ns, ho_ns, grad_output, go_owner, sum_n, out_ns, gi_index, True)
     _lib.check(rc, "cs%dd_%s" % (dim, stage))
-    _count(stage, want_grad_input)
+    _count(stage, want_grad_input, coherent)
     if g_leave:   # the plan now holds this one's sorted copy: remember whose, and keep it alive
         ctx._sorted_go = _Held(owner)
     if want_grad_input and ctx is not None and ctx.accumulate:
@@ -451,14 +452,32 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
 
 
 # ---- the order of the points ------------------------------------------------------------------------------------
-# Whether consecutive points share cells is a property of the caller's data.  'auto' (default) MEASURES it without ever
-# synchronising: a tiny kernel counts the tile changes of table 0's points (cs_points_tile_changes), the count comes back
-# through a pinned word behind an event, and the decision for a problem signature is the last count that has ARRIVED --
-# so the first call of a signature runs the general path and the decision follows the data one call late.  Both paths
-# give the same results for any order; only the time differs.
+# Whether consecutive points share cells is a property of the caller's DATA, and the coherent-points kernels are 20-40x
+# slower than the general path on unordered points (13-17 ms per scatter stage at BASELINE configs[1]): 'auto' (default)
+# therefore runs them ONLY on a grid tensor that has ITSELF been measured as ordered -- never on the strength of another
+# tensor's measurement (an equal shape says nothing: train / eval sets, two models, an ordered set followed by an unordered
+# one) and over ALL its points (every table of an (N,P,2) grid, not table 0).  The measurement is a 5 us kernel
+# (cs_points_tile_changes_sampled) whose count comes back through a pinned word behind an event:
+#   * a tensor seen before (identity + version counter, held while remembered): its decision, no work at all;
+#   * a new tensor: the measurement is enqueued.  If the LAST tensor of this problem signature turned out ordered -- the one
+#     case where waiting can pay: a caller whose steps rebuild the grid tensor from the same ordered points, as PIXEL's
+#     torch.cat([x, y]).repeat(...) does (reference test/test_2d.py:36-38) -- the host waits for the count (one
+#     event wait per new tensor; `order_waits` counts them) and then knows; otherwise nothing waits, the call takes the
+#     general path (always right) and the count is picked up by a later call with the same tensor.
+# So a wrong guess costs a missed speed-up or one wait, never the cliff.  Both paths give the same results for any order.
 _points_order = "auto"
-_order_state = {}       # signature -> [decision, measurement in flight, device word, pinned host word, event]
 MIN_COHERENT_SAMPLES = 1 << 16
+ORDER_SAMPLE_SEGMENTS = 64         # the order is judged on this many runs of 1024 consecutive points spread over the set (a 5 us kernel)
+ORDER_CACHE = 3                    # grid tensors whose decision is remembered (each is held alive while it is)
+ORDER_HISTORY = 64                 # problem signatures whose last decision is remembered
+order_waits = 0                    # how often the host waited for a measurement (tests, diagnostics)
+_order_known = []                  # _OrderEntry, most recent first
+_order_history = {}                # signature -> was the last measured tensor of this signature ordered?
+_order_pool = []                   # (device word, pinned host word, event) not in use
+
+
+class _OrderEntry(object):
+    __slots__ = ("held", "sig", "points", "decision", "slot")
 
 
 def points_order(mode=None):
@@ -468,41 +487,79 @@ def points_order(mode=None):
         if mode not in ("auto", "coherent", "random"):
             raise ValueError("points order must be 'auto', 'coherent' or 'random', got %r" % (mode,))
         _points_order = mode
-        _order_state.clear()
+        _order_reset()
     return _points_order
 
 
-ORDER_SAMPLE_SEGMENTS = 64         # the order is judged on this many runs of 1024 consecutive points spread over the set (a 5 us kernel)
+def _order_reset():
+    for e in _order_known:
+        if e.slot is not None:
+            _order_pool.append(e.slot)
+    del _order_known[:]
+    _order_history.clear()
+
+
+def _order_arrived(e):
+    e.decision = int(e.slot[1].item()) * 256 <= min(e.points, ORDER_SAMPLE_SEGMENTS * 1024)
+    _order_pool.append(e.slot)
+    e.slot = None
+    _order_history.pop(e.sig, None)
+    _order_history[e.sig] = e.decision
+    while len(_order_history) > ORDER_HISTORY:
+        _order_history.pop(next(iter(_order_history)))
 
 
 def _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream):
+    global order_waits
     mode = (ctx.points_order if ctx is not None and ctx.points_order else None) or _points_order
     if mode != "auto":
         return mode == "coherent"
     if shape[0] * P < MIN_COHERENT_SAMPLES:
         return False
-    sig = (grid.device, tuple(shape), P, int(padding_mode), bool(align_corners), bool(multicell))
-    st = _order_state.get(sig)
-    if st is None:
-        # decision, measurement in flight?, device word, pinned host word, event
-        st = _order_state[sig] = [False, False, torch.empty(1, dtype=torch.int32, device=grid.device),
-                                  torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event()]
-    Pm = min(P, ORDER_SAMPLE_SEGMENTS * 1024)
-    if st[1] and st[4].query():       # the measurement in flight has arrived
-        st[0] = int(st[3].item()) * 256 <= Pm
-        st[1] = False
-    # One measurement is in flight at any time, every call starts the next as soon as the last has arrived: the decision
-    # trails the data by a call or two.  That matters when a caller goes from an ordered set to an unordered one -- a
-    # stale 'coherent' costs an unordered call 20-40x its time (13-17 ms per stage at BASELINE configs[1], measured) --
-    # so the lag is kept as short as not synchronising allows.
-    if not st[1] and not torch.cuda.is_current_stream_capturing():
-        _lib.check(lib.cs_points_tile_changes_sampled(2, grid.data_ptr(), st[2].data_ptr(), P, 1, shape[-2], shape[-1],
-                                                      int(padding_mode), int(bool(align_corners)), int(bool(multicell)),
-                                                      ORDER_SAMPLE_SEGMENTS, stream), "cs_points_tile_changes_sampled")
-        st[3].copy_(st[2], non_blocking=True)
-        st[4].record()
-        st[1] = True
-    return st[0]
+    ent = None
+    for e in _order_known:                             # counts that have come back since the last call
+        if e.decision is None and e.slot[2].query():
+            _order_arrived(e)
+    for i, e in enumerate(_order_known):
+        if e.held.same(grid):
+            ent = e
+            if i:
+                _order_known.insert(0, _order_known.pop(i))
+            break
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():      # nothing can be read back inside a capture: the general path
+            return False
+        ent = _OrderEntry()
+        ent.held, ent.decision = _Held(grid), None
+        ent.sig = (grid.device, tuple(shape), tuple(grid.shape), int(padding_mode), bool(align_corners), bool(multicell))
+        ent.points = grid.numel() // 2               # every table's points, in the order the kernels would walk them
+        ent.slot = _order_pool.pop() if _order_pool else (torch.empty(1, dtype=torch.int32, device=grid.device),
+                                                          torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        if ent.slot[0].device != grid.device:
+            ent.slot = (torch.empty(1, dtype=torch.int32, device=grid.device), ent.slot[1], ent.slot[2])
+        _lib.check(lib.cs_points_tile_changes_sampled(2, grid.data_ptr(), ent.slot[0].data_ptr(), ent.points, 1, shape[-2],
+                                                      shape[-1], int(padding_mode), int(bool(align_corners)),
+                                                      int(bool(multicell)), ORDER_SAMPLE_SEGMENTS, stream),
+                   "cs_points_tile_changes_sampled")
+        ent.slot[1].copy_(ent.slot[0], non_blocking=True)
+        ent.slot[2].record()
+        _order_known.insert(0, ent)
+        for old in _order_known[ORDER_CACHE:]:
+            if old.slot is not None:
+                # (its measurement may still be in flight: the words are only re-used behind their own event)
+                old.slot[2].synchronize()
+                _order_pool.append(old.slot)
+        del _order_known[ORDER_CACHE:]
+    if ent.decision is None:
+        if ent.slot[2].query():
+            _order_arrived(ent)
+        elif _order_history.get(ent.sig, False) and not torch.cuda.is_current_stream_capturing():
+            ent.slot[2].synchronize()                  # the last tensor of this signature was ordered: worth knowing now
+            order_waits += 1
+            _order_arrived(ent)
+        else:
+            return False                               # in flight: the general path is right for any order
+    return ent.decision
 
 
 def points_tile_changes(points, size, padding_mode=0, align_corners=True, multicell=True):

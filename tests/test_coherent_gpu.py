@@ -264,30 +264,93 @@ def test_coherent_half_streams_vs_oracle(dtype):
         assert_close(got[k].float(), want[k], "coherent %s streams: %s" % (dtype, k), tol=tol16 if out16 else 1e-5)
 
 
-def test_auto_mode_follows_the_data_without_synchronising():
-    """'auto' measures the order behind an event: the first call of a signature runs the general path, later calls the
-    path the arrived measurement chose; results agree either way"""
+def _coherent_calls():
+    return sum(c[2] for c in ops.call_counts.values())
+
+
+def test_auto_mode_decides_per_tensor_and_never_from_another_tensors_measurement():
+    """'auto' runs the coherent kernels only on a grid tensor that was ITSELF measured as ordered (a stale 'coherent' on
+    unordered points costs 20-40x): a new tensor takes the general path unless the last tensor of its signature was
+    ordered, in which case the host waits for this tensor's own count; results agree on every path"""
     N, C, P, size = 4, 8, 40000, (64, 64)
     off = offsets(N, True).to(DEV)
-    ops.points_order("auto")
+    ops.points_order("auto")          # (also forgets every remembered tensor)
     ops.force_path(2)
     try:
-        ops._order_state.clear()
-        # the SAME signature throughout: the decision must follow the data from ordered to unordered and back within
-        # the three calls of each phase (a stale 'coherent' on unordered points is correct but 20-40x slower)
-        for how, expect in (("sorted", True), ("random", False), ("sorted", True)):
-            pts = _order(_points(P, 2, seed=23), size, how, 0, True, True, seed=1)
-            t = {k: v.to(DEV) for k, v in _case(N, C, size, pts, seed=6).items()}
-            res = []
-            for it in range(3):
-                res.append(ops.backward(t["gOut"], t["inp"], t["grid"], off, 0, True, True, 0, True, ctx=ops.StepContext()))
-                torch.cuda.synchronize()
-            (state,) = ops._order_state.values()
-            assert state[0] is expect, "decision for %s points: %r" % (how, state[0])
-            for gI, gG in res[1:]:
-                assert rel_err(gI, res[0][0]) <= 1e-5 and rel_err(gG, res[0][1]) <= 1e-5
+        def tensors(how, seed):
+            pts = _order(_points(P, 2, seed=seed), size, how, 0, True, True, seed=1)
+            return {k: v.to(DEV) for k, v in _case(N, C, size, pts, seed=6).items()}
+
+        def run(t):
+            before, waits = _coherent_calls(), ops.order_waits
+            r = ops.backward(t["gOut"], t["inp"], t["grid"], off, 0, True, True, 0, True, ctx=ops.StepContext())
+            torch.cuda.synchronize()
+            return r, _coherent_calls() - before, ops.order_waits - waits
+
+        srt, rnd, srt2 = tensors("sorted", 23), tensors("random", 23), tensors("sorted", 23)
+        r1, coh, waits = run(srt)
+        assert (coh, waits) == (0, 0), "first sight of a tensor, nothing known about its signature: general path, no wait"
+        r2, coh, waits = run(srt)
+        assert (coh, waits) == (1, 0), "the same tensor again: its own measurement has arrived"
+        r3, coh, waits = run(rnd)
+        assert (coh, waits) == (0, 1), "a NEW tensor after an ordered one: the host waits for ITS count -- unordered"
+        r4, coh, waits = run(rnd)
+        assert (coh, waits) == (0, 0)
+        r5, coh, waits = run(srt2)
+        assert (coh, waits) == (0, 0), "the last tensor of the signature was unordered: nothing waits, general path"
+        r6, coh, waits = run(srt2)
+        assert (coh, waits) == (1, 0)
+        # table 0 ordered, every other table not: the whole grid is measured, not table 0
+        mixed = dict(srt)
+        mixed["grid"] = torch.cat([srt["grid"][:1], rnd["grid"][1:]]).contiguous()
+        for _ in range(3):
+            _, coh, _w = run(mixed)
+            assert coh == 0, "a grid whose table 0 alone is ordered must not run on the coherent kernels"
+        for a, b in ((r1, r2), (r3, r4), (r5, r6), (r1, r5)):
+            assert rel_err(a[0], b[0]) <= 1e-5 and rel_err(a[1], b[1]) <= 1e-5
     finally:
         ops.force_path(0)
+        ops.points_order("auto")
+
+
+def test_auto_mode_has_no_cliff():
+    """no call in 'auto' mode costs more than 1.5x the general path: neither a grid whose first table alone is ordered, nor
+    the first unordered tensor after a run of ordered ones (the reference has no order-dependent cliff, 2d.cu:464-505)"""
+    N, C, P, size = 8, 16, 1 << 17, (128, 128)
+    off = offsets(N, True).to(DEV)
+    pts = _points(P, 2, seed=41)
+    srt = ops.sort_points(pts.to(DEV), size)[0]
+    g_rnd = pts.to(DEV).view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    g_srt = srt.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    g_mix = torch.cat([g_srt[:1], g_rnd[1:]]).contiguous()
+    gen = torch.Generator().manual_seed(3)
+    inp = torch.rand(N, C, *size, generator=gen).to(DEV)
+    gOut = torch.randn(N, C, 1, P, generator=gen).to(DEV)
+
+    def timed(grid, reps=1):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.backward(gOut, inp, grid, off, 0, True, True, 0, True, ctx=ops.StepContext())
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ops.points_order("random")
+    timed(g_rnd)
+    general = min(timed(g_rnd) for _ in range(3))
+    ops.points_order("auto")
+    try:
+        worst = max(timed(g_mix) for _ in range(4))
+        assert worst <= 1.5 * general, "table 0 ordered, the others not: %.3f ms vs %.3f ms general" % (worst, general)
+        for _ in range(3):
+            timed(g_srt)                                   # the signature's history now says 'ordered' ...
+        assert any(e.decision for e in ops._order_known)
+        fresh = g_rnd.clone()                              # ... and the next tensor is not
+        t = timed(fresh)
+        assert t <= 1.5 * general, "ordered -> unordered switch: %.3f ms vs %.3f ms general" % (t, general)
+    finally:
         ops.points_order("auto")
 
 
@@ -553,8 +616,7 @@ def test_full_size_helmholtz_autograd(order):
         (gc,) = torch.autograd.grad(loss, cells)
         return dict(u=u.detach(), u_x=u_x.detach(), u_xx=u_xx.detach(), u_yy=u_yy.detach(), gc=gc)
 
-    ops.points_order("auto")
-    ops._order_state.clear()
+    ops.points_order("auto")    # (forgets every remembered tensor and history)
     for _ in range(2):          # the order measurement arrives a call late
         step(False)
         torch.cuda.synchronize()
@@ -563,7 +625,7 @@ def test_full_size_helmholtz_autograd(order):
     smd = step(True, summed=True)
     torch.cuda.synchronize()
     if order == "sorted":
-        assert any(st[0] for st in ops._order_state.values()), "ordered points were not recognised"
+        assert any(e.decision for e in ops._order_known), "ordered points were not recognised"
         assert ops.sum_over_n_fused(cells0, xy.view(1, 1, P, 2), 0, True, True), "the summing kernels were not used"
     for k in rep:
         assert rel_err(bcr[k], rep[k]) <= 2e-5, "broadcast vs repeated grid: %s %.2e" % (k, rel_err(bcr[k], rep[k]))

@@ -118,3 +118,15 @@ def test_2d_forward_ignores_align_corners_quirk():
     a = cs_oracle.forward(inp, grid, off, 0, True, 0, True)
     b = cs_oracle.forward(inp, grid, off, 0, False, 0, True)
     assert torch.equal(a, b)
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """the CPU restatement under ASan / UBSan -- `make -C oracle asan-run` compiles cs_oracle.c into
+    oracle/asan_driver.c with -fsanitize=address,undefined and runs every function over exactly-sized heap buffers (all
+    padding modes, both align_corners settings, the three kernels, points far outside the range, optional tensors absent)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "asan-run"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "no finding" in r.stdout

@@ -21,7 +21,7 @@ elif [ "$1" = run ]; then
   shift
   for v in default "$@"; do
     if [ $v = default ]; then unset COSINESAMPLER_LIB; else export COSINESAMPLER_LIB=$R/cosinesampler_amd/lib/alt_$v.so; fi
-    python $R/bench.py --no-cpu-baseline --no-helmholtz --steps 10 --warmup 2 > /tmp/ab_$v.json
+    python $R/bench.py --no-cpu-baseline --no-helmholtz --steps ${STEPS:-20} --warmup 3 > /tmp/ab_$v.json
     python - $v /tmp/ab_$v.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
