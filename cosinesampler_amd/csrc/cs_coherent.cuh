@@ -433,7 +433,8 @@ struct Args {
 // The windows' global traffic (table rows in, atomics out) happens when the wave moves to another quad row: once per
 // ~4 batches of an ordered set.
 // `dbg`: experiments only, compiled in with -DCS_COH_DEBUG (cs_debug_coherent_tuning): 1 no scatter-reduce, 2 no window
-// flush, 4 no per-sample products, 32 no table-window loads, 64 no scatter operands written to LDS.
+// flush, 4 no per-sample products, 8 no stores of the output stream, 32 no table-window loads, 64 no scatter operands
+// written to LDS.
 // =====================================================================================================
 // COMMON: zeros padding with align_corners -- every BASELINE config and the reference's defaults -- as compile-time
 // constants: the padding variants are wave-uniform branches, but they cost scalar registers (the general kernels spill them
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256, (NSUM || CQ > 4) ? 2 : (half_batch(MODE) && SC
         const bool live = rel < count;
         if ((MODE == BWD || MODE == BB) && live)
             *at(reinterpret_cast<float2 *>(og_w), (uint32_t)rel * 8u) = make_float2(r.gx, r.gy);
-        if (OUTS && live) {
+        if (OUTS && live && !(dbg & 8)) {
             LaneOffs lo;
             lo.set((uint32_t)rel * (uint32_t)sizeof(ST), ro);
             if (ro.Cv == C) {

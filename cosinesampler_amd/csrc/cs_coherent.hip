@@ -13,7 +13,15 @@ namespace coh {
 int launch_nsum(int mode, bool two, bool scat, const Launch &L, const Args &a, int dbg);
 namespace {
 
-std::atomic<int> g_dbg{0}, g_chunk{512}, g_wpb{1};
+std::atomic<int> g_dbg{0}, g_chunk{0}, g_wpb{1};      // g_chunk 0: the per-stage defaults below
+// samples per wave.  A wave pays one table-window load when it starts, so longer chunks amortise better, but the grid is
+// ~12 rounds of single-wave workgroups and shorter chunks leave a smaller idle tail: measured at BASELINE configs[1]
+// (tools/coh_sweep.sh, 128 ... 2048): the forward 0.217 ms at 384 against 0.241 at 512, second / third backward 1-2 %
+// better at 384, the first backward 2 % better at 512.
+#ifndef CS_COH_CHUNKS
+#define CS_COH_CHUNKS {384, 512, 384, 384}
+#endif
+constexpr int kChunk[4] = CS_COH_CHUNKS;
 #ifndef CS_COH_LDS_EXTRA
 #define CS_COH_LDS_EXTRA 0     // experiments (tools/ab.sh): unused LDS bytes per wave, to cap the waves a CU holds
 #endif
@@ -32,9 +40,10 @@ struct Geometry {
     dim3 grid;
     int block, chunk, dbg;
 };
-Geometry geometry(const Launch &L) {
+Geometry geometry(const Launch &L, int mode) {
     Geometry g;
     g.chunk = g_chunk.load(std::memory_order_relaxed);
+    if (g.chunk <= 0) g.chunk = kChunk[mode];
     g.dbg = g_dbg.load(std::memory_order_relaxed);
     const int64_t waves = (L.d.P + g.chunk - 1) / g.chunk;
     const int wpb = g_wpb.load(std::memory_order_relaxed);
@@ -66,7 +75,7 @@ Geometry geometry(const Launch &L) {
 template <int MODE, bool TWO, bool SCAT = true>
 int launch(const Launch &L, const Args &a) {
     if (L.nsum) return launch_nsum(MODE, TWO, SCAT, L, a, g_dbg.load(std::memory_order_relaxed));   // cs_coherent_sum.hip
-    const Geometry g = geometry(L);
+    const Geometry g = geometry(L, MODE);
     int rc = 0;
 #ifndef CS_COH_NO_COMMON
     if (L.sdt == 0 && L.f.pad == PAD_ZEROS && L.f.align) {     // fp32 streams, zeros padding, align_corners: the specialised kernels
@@ -90,7 +99,7 @@ int launch(const Launch &L, const Args &a) {
 }  // namespace
 
 void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no products
-    if (samples_per_wave >= 64) g_chunk.store((samples_per_wave + 63) / 64 * 64, std::memory_order_relaxed);
+    g_chunk.store(samples_per_wave >= 64 ? (samples_per_wave + 63) / 64 * 64 : 0, std::memory_order_relaxed);
     g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 15) << 3, std::memory_order_relaxed);     // + 256 / 512: store policies (unused now), + 1024: no table-window loads, + 2048: no scatter operands to LDS
     if (((ablation_bits >> 4) & 15) >= 1 && ((ablation_bits >> 4) & 15) <= 4) g_wpb.store((ablation_bits >> 4) & 15, std::memory_order_relaxed);   // waves per workgroup
 }

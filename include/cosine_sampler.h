@@ -237,7 +237,7 @@ int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_
 int cs_points_tile_changes_sampled(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H,
                                    int64_t W, int padding_mode, int align_corners, int multicell, int segments,
                                    void *stream);
-/* Tuning / experiments on the coherent kernels: samples_per_wave (a multiple of 64; 0 keeps the value) and ablation_bits,
+/* Tuning / experiments on the coherent kernels: samples_per_wave (a multiple of 64; 0: the per-stage defaults) and ablation_bits,
  * which switch parts of the kernels OFF to see what each costs (results are then wrong): 1 no scatter-reduce, 2 no window
  * flush, 4 no products / outputs; 0 = the product.  Process-wide.  INERT unless COSINESAMPLER_DEBUG=1 was in the
  * environment when the library was first used, and the ablation bits only exist in a library built with -DCS_COH_DEBUG
