@@ -991,7 +991,7 @@ template <int MODE>
 int tiles3_scatter(const Problem &pb, const tl::Plan &pl, const float *rows, float *grad_input) {
     const int CP = (int)cpad(pb.d.C);
     const int waves = CP <= 8 ? 4 : 2;                                   // 4 / 8 / 16 KiB of LDS image per wave
-    const size_t shm = (size_t)waves * t3::OWNED * CP * 4;
+    const size_t shm = (size_t)waves * (t3::OWNED * CP + t3::CNT_WORDS) * 4;   // images + the waves' code counters
     const int64_t nb = (int64_t)pb.d.N * pl.ntiles;
     CS_DISPATCH_CQ(pb.d.C, (t3::tile3_scatter<CQ, MODE><<<(unsigned)((nb + waves - 1) / waves), 64 * waves, shm, pb.stream>>>(
                                rows, pl, grad_input, pb.d, waves)));

@@ -169,12 +169,13 @@ struct Windows {
         return (int)(key & 0x7FFCu) == tqx && (int)(key >> 15) == aqy;
     }
     __device__ __forceinline__ int column(uint32_t key) const { return 2 * ((int)(key & 0x7FFFu) - tqx); }
-    // nodes outside the table read as zero (zero padding)
-    __device__ __forceinline__ void load_table(const float *__restrict__ tab_n, const Dims &d) {
+    // nodes outside the table read as zero (zero padding).  In two halves: the loads go out when the wave knows where it
+    // moves, the rows land in LDS after the old accumulator window has been flushed -- the flush (LDS reads, atomics)
+    // runs inside the loads' round trip instead of in front of it.
+    static constexpr int Q = WN * L::CQ;                    // float4 per window row
+    static constexpr int NV = (WNY * Q + 63) / 64;
+    __device__ __forceinline__ void load_issue(const float *__restrict__ tab_n, const Dims &d, float4 (&v)[NV]) const {
         const int lane = threadIdx.x & 63;
-        constexpr int Q = WN * L::CQ;                       // float4 per window row
-        constexpr int NV = (WNY * Q + 63) / 64;
-        float4 v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = i * 64 + lane, iy = idx / Q, c4 = idx - iy * Q;
@@ -184,6 +185,9 @@ struct Windows {
             v[i] = *src;
             if (!ok) v[i] = tl::zero4();
         }
+    }
+    __device__ __forceinline__ void load_land(const float4 (&v)[NV]) {
+        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = i * 64 + lane, iy = idx / Q, c4 = idx - iy * Q;
@@ -191,7 +195,8 @@ struct Windows {
         }
     }
     // AW -> the channels-last accumulator, WN*C contiguous floats per row: whole-line float atomics; AW is left zero
-    __device__ __forceinline__ void flush(float *__restrict__ acc_n, const Dims &d) {
+    __device__ __forceinline__ void flush(float *__restrict__ acc_n, const Dims &d) { flush_at(acc_n, d, tqx, aqy); }
+    __device__ __forceinline__ void flush_at(float *__restrict__ acc_n, const Dims &d, int tqx, int aqy) {
         if (!ACC || !dirty) return;
         dirty = false;
         const int lane = threadIdx.x & 63;
@@ -216,11 +221,19 @@ struct Windows {
     // move both windows to the quad row of `key`
     __device__ __forceinline__ void anchor(uint32_t key, const float *__restrict__ tab_n, float *__restrict__ acc_n,
                                            const Dims &d) {
-        flush(acc_n, d);
+        const int otqx = tqx, oaqy = aqy;
         tqx = (int)(key & 0x7FFCu);
         aqy = (int)(key >> 15);
+        float4 v[NV];
+#ifdef CS_COH_NO_ANCHOR_OVERLAP      // A/B builds: the flush in front of the loads, as before
+        flush_at(acc_n, d, otqx, oaqy);
+        if (!noload) load_issue(tab_n, d, v);
+#else
+        if (!noload) load_issue(tab_n, d, v);
+        flush_at(acc_n, d, otqx, oaqy);
+#endif
         wave_sync();
-        if (!noload) load_table(tab_n, d);
+        if (!noload) load_land(v);
         wave_sync();
     }
 };
@@ -355,13 +368,16 @@ __device__ __forceinline__ T load_elem(rsrc_t r, uint32_t voff, uint32_t soff) {
 }
 // outputs leave nontemporal: the table is read through the windows, nothing here wants to stay in the L2 (forward:
 // 0.300 -> 0.242 ms against write-through stores, the other stages unchanged)
+#ifndef CS_COH_OUT_AUX
+#define CS_COH_OUT_AUX 2      // cache policy of the output stores: 2 nontemporal, 16 sc1 (write-through), 0 plain (A/B builds)
+#endif
 template <typename T>
 __device__ __forceinline__ void store_elem(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
     const T t = (T)v;
     if constexpr (sizeof(T) == 4) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), r, (int)voff, (int)soff, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), r, (int)voff, (int)soff, CS_COH_OUT_AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), r, (int)voff, (int)soff, 2);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, t), r, (int)voff, (int)soff, CS_COH_OUT_AUX);
     }
 }
 // channel c of this lane's sample; channels >= Cv do not exist (C padded up to a supported count)

@@ -15,11 +15,13 @@ namespace {
 
 std::atomic<int> g_dbg{0}, g_chunk{0}, g_wpb{1};      // g_chunk 0: the per-stage defaults below
 // samples per wave.  A wave pays one table-window load when it starts, so longer chunks amortise better, but the grid is
-// ~12 rounds of single-wave workgroups and shorter chunks leave a smaller idle tail: measured at BASELINE configs[1]
-// (tools/coh_sweep.sh, 128 ... 2048): the forward 0.217 ms at 384 against 0.241 at 512, second / third backward 1-2 %
-// better at 384, the first backward 2 % better at 512.
+// ~12 rounds of single-wave workgroups and shorter chunks leave a smaller idle tail.  Swept INSIDE the step (tools/
+// chunk_sweep.sh: the ordered-points step of bench.py; a stage timed back to back with itself ranks them differently --
+// profiles/round4_ablation.txt): forward 0.322 / 0.293 / 0.278 / 0.329 / 0.346 ms at 128 / 192 / 256 / 384 / 512 (256 = the
+// four batches of coordinates it keeps in flight: every load of the wave goes out at once), first backward 0.358 / 0.342 /
+// 0.347 at 256 / 384 / 512, second 0.557 / 0.548 / 0.561, third 0.836 / 0.819 / 0.824.
 #ifndef CS_COH_CHUNKS
-#define CS_COH_CHUNKS {384, 512, 384, 384}
+#define CS_COH_CHUNKS {256, 384, 384, 384}
 #endif
 constexpr int kChunk[4] = CS_COH_CHUNKS;
 #ifndef CS_COH_LDS_EXTRA
@@ -43,6 +45,7 @@ struct Geometry {
 Geometry geometry(const Launch &L, int mode) {
     Geometry g;
     g.chunk = g_chunk.load(std::memory_order_relaxed);
+    if (g.chunk >= (1 << 16)) g.chunk = 64 * ((g.chunk >> (8 * mode)) & 0xFF);   // experiments: one byte per stage, in batches of 64
     if (g.chunk <= 0) g.chunk = kChunk[mode];
     g.dbg = g_dbg.load(std::memory_order_relaxed);
     const int64_t waves = (L.d.P + g.chunk - 1) / g.chunk;
@@ -99,7 +102,9 @@ int launch(const Launch &L, const Args &a) {
 }  // namespace
 
 void set_chunk(int samples_per_wave, int ablation_bits) {   // experiments: 1 no scatter-reduce, 2 no window flush, 4 no products
-    g_chunk.store(samples_per_wave >= 64 ? (samples_per_wave + 63) / 64 * 64 : 0, std::memory_order_relaxed);
+    // (values from 2^16 up: four bytes, one per stage, forward in the lowest: the samples per wave of that stage in batches of 64)
+    g_chunk.store(samples_per_wave >= (1 << 16) ? samples_per_wave : samples_per_wave >= 64 ? (samples_per_wave + 63) / 64 * 64 : 0,
+                  std::memory_order_relaxed);
     g_dbg.store((ablation_bits & 7) | ((ablation_bits >> 8) & 15) << 3, std::memory_order_relaxed);     // + 256 / 512: store policies (unused now), + 1024: no table-window loads, + 2048: no scatter operands to LDS
     if (((ablation_bits >> 4) & 15) >= 1 && ((ablation_bits >> 4) & 15) <= 4) g_wpb.store((ablation_bits >> 4) & 15, std::memory_order_relaxed);   // waves per workgroup
 }

@@ -292,16 +292,17 @@ struct Batch3 {   // one lane's share of a batch: a sample's row
         }
     }
 };
+constexpr int CNT_WORDS = 128;     // per wave: one byte counter per code (BINS / 4 words), kept zero between batches
 // add one batch (lane = list entry) to the wave's image [z][y][x][CQ]
 template <int CQ, int MODE>
-__device__ __forceinline__ void sum_batch3(float4 *img, const Batch3<CQ, MODE> &b, int code, bool live) {
-    const int lane = threadIdx.x & 63;
-    // rank of this entry among the entries of the batch with the same code (the bucket is in no particular order: 64
-    // lane reads and compares cost less than sorting every bucket in the plan did -- 0.16 ms per step at config 3)
-    const int mycode = live ? code : -1 - lane;
+__device__ __forceinline__ void sum_batch3(float4 *img, uint32_t *cnt, const Batch3<CQ, MODE> &b, int code, bool live) {
+    // rank of this entry among the entries of the batch with the same code (the bucket is in no particular order): a
+    // returning LDS add on the code's byte counter hands every entry of a code a different rank -- one instruction where
+    // the first version read and compared all 63 other lanes' codes (~190 instructions per batch; the kernel is bound by
+    // the instructions its short waves issue: profiles/round4_ablation.txt).  The entries put their counters back to zero.
     int rank = 0;
-#pragma unroll
-    for (int l = 0; l < 63; ++l) rank += (l < lane && __builtin_amdgcn_readlane(mycode, l) == mycode) ? 1 : 0;
+    const int sh = 8 * (code & 3);
+    if (live) rank = (int)((atomicAdd(&cnt[code >> 2], 1u << sh) >> sh) & 0xFFu);
     int maxrank = rank;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) maxrank = max(maxrank, __shfl_xor(maxrank, m));
@@ -332,6 +333,8 @@ __device__ __forceinline__ void sum_batch3(float4 *img, const Batch3<CQ, MODE> &
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ranks of one code follow each other
     }
+    if (live) cnt[code >> 2] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 template <int CQ, int MODE>
 __global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ rows, Plan pl, float *__restrict__ out,
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ r
     if (bucket >= (int64_t)d.N * pl.ntiles) return;
     float4 *img = img_all + wv * (OWNED * CQ);     // this wave's image: LDS operations of ONE wave execute in order,
                                                    // so no barrier is needed anywhere below
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(img_all + waves * (OWNED * CQ)) + wv * CNT_WORDS;   // the wave's code counters
+    for (int i = lane; i < CNT_WORDS; i += 64) cnt[i] = 0u;
     const uint32_t b0 = pl.tile_begin[bucket], b1 = pl.tile_begin[bucket + 1];
     const uint32_t sbase = (uint32_t)(bucket / pl.ntiles) * (uint32_t)d.P;          // n * P
     for (int i = lane; i < OWNED * CQ; i += 64) img[i] = cl::zero4();
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ r
         Batch3<CQ, MODE> A, B;
         A.load(rows, sbase + (kA >> 9));
         B.load(rows, sbase + (kB >> 9));
-        sum_batch3<CQ, MODE>(img, A, codeA, liveA);
-        if (j0 + 64 < b1) sum_batch3<CQ, MODE>(img, B, codeB, liveB);
+        sum_batch3<CQ, MODE>(img, cnt, A, codeA, liveA);
+        if (j0 + 64 < b1) sum_batch3<CQ, MODE>(img, cnt, B, codeB, liveB);
     }
     // the tile leaves: rows of 16 nodes along x of one (channel, z, y), 64 contiguous bytes each
     const int W = d.size[0], H = d.size[1], D = d.size[2];
@@ -365,23 +370,33 @@ __global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ r
     tl /= pl.ntx;
     const int ty = tl % pl.nty, tz = tl / pl.nty;
     const int x0 = tx * M3X, y0 = ty * M3Y, z0 = tz * M3Z;
-    const float *imf = reinterpret_cast<const float *>(img);
     float *o = out + (int64_t)n * d.C * d.vol;
     const bool vec = (W & 3) == 0;
-    for (int i = lane; i < CP * M3Z * M3Y * (M3X / 4); i += 64) {     // one float4 of x per item
-        const int x4 = i % (M3X / 4), r = i / (M3X / 4), y = r % M3Y, zc = r / M3Y, z = zc % M3Z, c = zc / M3Z;
+    // one item = the four channels of a quad at four nodes along x: four 16-byte LDS reads, four 16-byte stores (one per
+    // channel plane) -- the first version took one channel per item with four scalar LDS reads each: four times the loop
+    // iterations and index arithmetic for the same stores
+    for (int i = lane; i < CQ * M3Z * M3Y * (M3X / 4); i += 64) {
+        const int x4 = i % (M3X / 4), r = i / (M3X / 4), y = r % M3Y, zq = r / M3Y, z = zq % M3Z, q = zq / M3Z;
         const int gx = x0 + 4 * x4, gy = y0 + y, gz = z0 + z;
-        if (c >= d.C || gy >= H || gz >= D || gx >= W) continue;
-        const float *src = imf + (((z * M3Y + y) * M3X + 4 * x4) * CQ) * 4 + c;     // channel c of 4 nodes
-        const float4 v = make_float4(src[0], src[CP], src[2 * CP], src[3 * CP]);
-        float *dst = o + (int64_t)c * d.vol + ((int64_t)gz * H + gy) * W + gx;
-        if (vec) {
-            *reinterpret_cast<float4 *>(dst) = v;                     // W % 4 == 0: whole quads are in range
-        } else {
-            dst[0] = v.x;
-            if (gx + 1 < W) dst[1] = v.y;
-            if (gx + 2 < W) dst[2] = v.z;
-            if (gx + 3 < W) dst[3] = v.w;
+        if (gy >= H || gz >= D || gx >= W) continue;
+        const float4 *src = img + ((z * M3Y + y) * M3X + 4 * x4) * CQ + q;
+        const float4 n0 = src[0], n1 = src[CQ], n2 = src[2 * CQ], n3 = src[3 * CQ];
+        const float4 ch[4] = {make_float4(n0.x, n1.x, n2.x, n3.x), make_float4(n0.y, n1.y, n2.y, n3.y),
+                              make_float4(n0.z, n1.z, n2.z, n3.z), make_float4(n0.w, n1.w, n2.w, n3.w)};
+        float *dst0 = o + (int64_t)(4 * q) * d.vol + ((int64_t)gz * H + gy) * W + gx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (4 * q + k >= d.C) break;
+            float *dst = dst0 + (int64_t)k * d.vol;
+            const float4 v = ch[k];
+            if (vec) {
+                *reinterpret_cast<float4 *>(dst) = v;                     // W % 4 == 0: whole quads are in range
+            } else {
+                dst[0] = v.x;
+                if (gx + 1 < W) dst[1] = v.y;
+                if (gx + 2 < W) dst[2] = v.z;
+                if (gx + 3 < W) dst[3] = v.w;
+            }
         }
     }
 }

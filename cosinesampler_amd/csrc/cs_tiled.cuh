@@ -602,22 +602,43 @@ __device__ __forceinline__ void put_payload(float *row, const float4 (&g)[CQ]) {
 #pragma unroll
     for (int q = 0; q < CQ; ++q) *reinterpret_cast<float4 *>(row + 4 * q) = g[q];
 }
+// 16-byte stores of p-ordered records and of the sorted grad_output copy: through a buffer descriptor of the wave's /
+// workgroup's own range (wave-uniform base, 32-bit lane offset) so that the cache policy is a parameter -- aux 2 =
+// nontemporal, 16 = sc1 (written through and dropped from the XCD's L2), 0 = plain.
+#ifndef CS_ROWS_AUX
+#define CS_ROWS_AUX 2
+#endif
+#ifndef CS_EMIT_AUX
+#define CS_EMIT_AUX 0
+#endif
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+template <int AUX>
+__device__ __forceinline__ void st_row16(__amdgpu_buffer_rsrc_t r, uint32_t byteoff, float4 v) {
+    const v4f_t t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, t), r, (int)byteoff, 0, AUX);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *uniform_base) {
+    const uint64_t a = (uint64_t)uniform_base;       // wave-uniform by construction; say so to the compiler
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, -1, 0x00020000);
+}
 template <int STRIDE>
 __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n, const Dims &d) {
     const int lane = threadIdx.x & 63;
     const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first point of this wave
     if (p0 >= d.P) return;
     const int nlive = (int)min((int64_t)64, d.P - p0);
-    float4 *dst = reinterpret_cast<float4 *>(fat + ((int64_t)n * d.P + p0) * STRIDE);
+    const __amdgpu_buffer_rsrc_t dst = rows_rsrc(fat + ((int64_t)n * d.P + p0) * STRIDE);
     const float4 *src = reinterpret_cast<const float4 *>(stage);
     constexpr int PIECES = STRIDE / 4;                                        // float4 per row
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         int item = i * 64 + lane;
-        if (item < nlive * PIECES) {   // nontemporal: the rows are next read by the tile kernel, long after they left
-            typedef float v4f __attribute__((ext_vector_type(4)));   // the caches (-0.28 ms per step against plain stores)
-            __builtin_nontemporal_store(reinterpret_cast<const v4f *>(src)[item], reinterpret_cast<v4f *>(dst) + item);
-        }
+        // nontemporal: the rows are next read by the tile kernel, long after they left the caches (-0.28 ms per step
+        // against plain stores)
+        if (item < nlive * PIECES) st_row16<CS_ROWS_AUX>(dst, (uint32_t)item * 16u, src[item]);
     }
 }
 
@@ -772,9 +793,8 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
         }
         *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
         if (ROWS == 2 && sm.live) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f t = {Dm[0], Dm[1], Dm[2], Dm[3]};
-            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(fat + sm.s * 4));
+            const int64_t s0w = (int64_t)sm.n * d.P + wave_p0();          // the wave's first sample: uniform
+            st_row16<CS_ROWS_AUX>(rows_rsrc(fat + s0w * 4), (uint32_t)(threadIdx.x & 63) * 16u, make_float4(Dm[0], Dm[1], Dm[2], Dm[3]));
         }
         q_put_nodes(rec, sm);
     }
@@ -945,6 +965,7 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
         uint32_t nb = cbr[1];                   // first position of the next cell
         const uint32_t *sorted = pl.sorted + b0;
         float *gs = pl.Gs + (int64_t)b0 * C + 4 * q;     // this bucket's rows of the sorted gOut copy, this lane's quad
+        const __amdgpu_buffer_rsrc_t gs_r = rows_rsrc(pl.Gs + (int64_t)b0 * C);   // (the same rows, for the EMIT stores)
         const uint32_t jbeg = cbr[0];
         uint32_t ids[U];                        // sample ids of the NEXT batch: fetched one batch ahead so that
 #pragma unroll                                  // the row fetches never wait on the id fetch
@@ -976,7 +997,7 @@ __global__ __launch_bounds__(256) void tile_scatter(const float *__restrict__ fa
             if (EMIT) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (j + u < j1) *reinterpret_cast<float4 *>(gs + (int64_t)(j + u) * C) = g[u];
+                    if (j + u < j1) st_row16<CS_EMIT_AUX>(gs_r, (uint32_t)(((j + u) * C + 4 * q) * 4), g[u]);
             }
             if (j + U < j1) {
 #pragma unroll

@@ -147,3 +147,35 @@ def test_debug_knobs_cannot_make_the_shipped_library_wrong():
         assert_close(gI, want, "grad_input with ablation bits requested")
     finally:
         lib.cs_debug_coherent_tuning(0, 0)
+
+
+def test_a_helmholtz_step_scatters_only_where_the_engine_asked():
+    """BASELINE configs[2]'s call pattern through torch.autograd (reference test/test_2d.py:55-127, :221-240): the graph
+    runs 11 sampler stages and only 5 of them produce an input-shaped gradient -- the derivatives taken with
+    autograd.grad(u, x, create_graph=True) never use d/d cells, and the autograd layer asks the engine
+    (functions._engine_wants, a private torch hook) before scattering.  If that question silently stops being answered,
+    every stage scatters again (the reference's behaviour: correct, several ms slower): this count catches it."""
+    from cosinesampler_amd import CosineSampler2d
+    N, C, H, P = 4, 8, 32, 20000
+    g = torch.Generator().manual_seed(5)
+    cells = torch.rand(N, C, H, H, generator=g).to(DEV).requires_grad_(True)
+    W1 = (torch.randn(16, C, generator=g) * 0.5).to(DEV)
+    W2 = (torch.randn(1, 16, generator=g) * 0.5).to(DEV)
+    x = (torch.rand(P, 1, generator=g) * 2 - 1).to(DEV).requires_grad_(True)
+    y = (torch.rand(P, 1, generator=g) * 2 - 1).to(DEV).requires_grad_(True)
+    ones = torch.ones(P, 1, device=DEV)
+    ops.call_counts.clear()
+    grid = torch.cat([x, y], -1).view(1, 1, P, 2).repeat(N, 1, 1, 1)
+    feat = CosineSampler2d.apply(cells, grid, "zeros", True, "cosine", True).sum(0)
+    u = torch.tanh(feat.view(C, -1).t() @ W1.t()) @ W2.t()
+    u_x, u_y = torch.autograd.grad(u, (x, y), ones, create_graph=True)
+    (u_xx,) = torch.autograd.grad(u_x, x, ones, create_graph=True)
+    (u_yy,) = torch.autograd.grad(u_y, y, ones, create_graph=True)
+    before = {k: list(v) for k, v in ops.call_counts.items()}
+    assert sum(v[1] for v in before.values()) == 0, "taking u_x, u_xx scattered: %r" % before
+    loss = torch.mean((u_xx + u_yy + 4.0 * u) ** 2)
+    (gc,) = torch.autograd.grad(loss, cells)
+    torch.cuda.synchronize()
+    calls = sum(v[0] for v in ops.call_counts.values())
+    scattered = sum(v[1] for v in ops.call_counts.values())
+    assert (calls, scattered) == (11, 5), "sampler stages / of which scattering: %r" % ops.call_counts

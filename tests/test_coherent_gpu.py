@@ -281,22 +281,24 @@ def test_auto_mode_decides_per_tensor_and_never_from_another_tensors_measurement
             pts = _order(_points(P, 2, seed=seed), size, how, 0, True, True, seed=1)
             return {k: v.to(DEV) for k, v in _case(N, C, size, pts, seed=6).items()}
 
-        def run(t):
+        def run(t, busy=False):
             before, waits = _coherent_calls(), ops.order_waits
+            if busy:          # the GPU has ~10 ms of other work queued: a count asked for now cannot be back when the op looks
+                torch.cuda._sleep(20_000_000)
             r = ops.backward(t["gOut"], t["inp"], t["grid"], off, 0, True, True, 0, True, ctx=ops.StepContext())
             torch.cuda.synchronize()
             return r, _coherent_calls() - before, ops.order_waits - waits
 
         srt, rnd, srt2 = tensors("sorted", 23), tensors("random", 23), tensors("sorted", 23)
-        r1, coh, waits = run(srt)
+        r1, coh, waits = run(srt, busy=True)
         assert (coh, waits) == (0, 0), "first sight of a tensor, nothing known about its signature: general path, no wait"
         r2, coh, waits = run(srt)
         assert (coh, waits) == (1, 0), "the same tensor again: its own measurement has arrived"
-        r3, coh, waits = run(rnd)
+        r3, coh, waits = run(rnd, busy=True)
         assert (coh, waits) == (0, 1), "a NEW tensor after an ordered one: the host waits for ITS count -- unordered"
         r4, coh, waits = run(rnd)
         assert (coh, waits) == (0, 0)
-        r5, coh, waits = run(srt2)
+        r5, coh, waits = run(srt2, busy=True)
         assert (coh, waits) == (0, 0), "the last tensor of the signature was unordered: nothing waits, general path"
         r6, coh, waits = run(srt2)
         assert (coh, waits) == (1, 0)

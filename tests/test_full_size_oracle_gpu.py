@@ -122,3 +122,56 @@ def test_full_size_helmholtz_step_matches_the_oracle_backed_chain(monkeypatch):
     want = step("cpu")
     for k in ("u", "u_x", "u_y", "u_xx", "u_yy", "gc"):
         assert_close(got[k], want[k], "Helmholtz step, %s" % k, 1e-5)
+
+
+def test_streams_of_two_to_the_31_elements():
+    """The case the reference instantiates its 64-bit-index kernels for (2d.cu:906-933: canUse32BitIndexMath fails once a
+    tensor holds 2^31 elements): N=16 C=16 64^2 P=2^23 -- every channel-major stream has exactly 2^31 elements (8 GiB).
+    forward + backward + fused third backward on the points as drawn (plan, records, walkers: 64-bit element offsets,
+    32-bit sample ids) against the CPU oracle: the whole grad_input of both scatter stages and slices of every p-ordered
+    output; then the same points in cell order (coherent kernels, 32-bit buffer offsets) must give the same grad_input."""
+    N, C, H, P, K = 16, 16, 64, 1 << 23, 4096
+    assert N * C * P == 1 << 31
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    inp = torch.rand(N, C, H, H, device=DEV, generator=g)
+    xy = torch.rand(P, 2, device=DEV, generator=g) * 2 - 1
+    grid = xy.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    gOut = torch.randn(N, C, 1, P, device=DEV, generator=g)
+    hO = torch.randn(N, C, 1, P, device=DEV, generator=g)
+    cG = torch.randn(N, 1, P, 2, device=DEV, generator=g)
+    hG = torch.randn(N, 1, P, 2, device=DEV, generator=g)
+    off = multicell_offset(N, True, DEV)
+    sc = ops.StepContext(points_order="random")
+    out = ops.forward(inp, grid, off, 0, True, 0, True, ctx=sc)
+    gI, gG = ops.backward(gOut, inp, grid, off, 0, True, True, 0, True, ctx=sc)
+    tI, tO = ops.bbb_fused(inp, grid, gOut, cG, hG, hO, off, 0, True, 0, True, ctx=sc)
+    torch.cuda.synchronize()
+    del sc
+    # slices of the p-ordered outputs: the last table (the highest element offsets), points from the far end
+    n, sl = N - 1, slice(P - K, P)
+    c_inp, c_off = inp[n:n + 1].cpu(), off[n:n + 1].cpu()
+    c_grid = grid[n:n + 1, :, sl].contiguous().cpu()
+    ps = lambda t: t[n:n + 1, :, :, sl].contiguous().cpu()
+    gs = lambda t: t[n:n + 1, :, sl].contiguous().cpu()
+    assert_close(ps(out), cs_oracle.forward(c_inp, c_grid, c_off, 0, True, 0, True), "2^31: forward slice")
+    assert_close(gs(gG), cs_oracle.backward(ps(gOut), c_inp, c_grid, c_off, 0, True, True, 0, True)[1], "2^31: grad_grid slice")
+    assert_close(ps(tO), cs_oracle.bbb_fused(c_inp, c_grid, ps(gOut), gs(cG), gs(hG), ps(hO), c_off, 0, True, 0, True)[1],
+                 "2^31: third-backward grad_grad_out slice")
+    del out, tO, gG
+    # the same points in cell order on the coherent kernels: grad_input does not depend on the order of the points
+    xy_s, perm = ops.sort_points(xy, (H, H))
+    grid_s = xy_s.view(1, 1, P, 2).repeat(N, 1, 1, 1).contiguous()
+    sc = ops.StepContext(points_order="coherent")
+    gI_s, _ = ops.backward(gOut[..., perm].contiguous(), inp, grid_s, off, 0, True, True, 0, True, ctx=sc)
+    torch.cuda.synchronize()
+    assert_close(gI_s, gI, "2^31: coherent kernels, grad_input", 2e-6 * 8)      # 2^17 terms per node, two summation orders
+    del gI_s, grid_s, sc, xy_s, perm
+    torch.cuda.empty_cache()
+    # the whole input-shaped gradients against the oracle (double accumulation: 2^17 terms per node)
+    c = lambda t: t.cpu()
+    with cs_oracle.double_accumulation():
+        w_gI = cs_oracle.backward(c(gOut), c(inp), c(grid), c(off), 0, True, True, 0, True)[0]
+        assert_close(gI, w_gI, "2^31: backward grad_input")
+        del w_gI
+        w_tI = cs_oracle.bbb_fused(c(inp), c(grid), c(gOut), c(cG), c(hG), c(hO), c(off), 0, True, 0, True)[0]
+        assert_close(tI, w_tI, "2^31: third-backward grad_input")
