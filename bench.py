@@ -541,8 +541,9 @@ def main():
             line["pixel_helmholtz_autograd"]["ms_per_step_summed_op"] = helmholtz_step(N, C, H, P, dev, summed_op=True)
             line["pixel_helmholtz_autograd"]["summed_op"] = (
                 "the same step with features = CosineSampler2dSum.apply(cells, points) instead of "
-                "CosineSampler2d.apply(cells, points.repeat(N,1,1,1)).sum(0): on ordered points the summing kernels (CS_SUM_OVER_N) "
-                "run and no (N,C,P) tensor exists anywhere in the step; on drawn points the plain op and torch sums do the work")
+                "CosineSampler2d.apply(cells, points.repeat(N,1,1,1)).sum(0): the summing kernels (CS_SUM_OVER_N) run and no (N,C,P) "
+                "tensor exists anywhere in the step; points in the order they were drawn are put into cell order inside the op "
+                "(one sort of the P points per step, the (1,C,P) cotangents and results carried over with index selections)")
             from cosinesampler_amd import ops as _ops
             _ops.plan_cache(1)
             try:

@@ -886,26 +886,83 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
 # features = sampler(cells, grid.repeat(N,1,1,1)).sum(0) (reference test/test_2d.py:38, :51): one set of points, and -- in
 # every derivative the caller takes -- one cotangent for all N tables and results that are summed over them.  These four
 # functions take and return the n-free tensors ((1,C,..,P) streams, (1,..,P,dim) grid-shaped); input-shaped gradients stay
-# (N,C,H,W).  Where the summing kernels apply (2D fast path, fp32, zeros padding with align_corners, N > 1, C <= 32) and the
-# points are in cell order they run as ONE kernel per stage that never materialises an (N,C,P) stream; anywhere else the
-# same values come from the plain op on expanded inputs followed by torch sums.
+# (N,C,H,W).  Where the summing kernels apply (2D fast path, fp32, zeros padding with align_corners, N > 1, C <= 32) they run
+# as ONE kernel per stage that never materialises an (N,C,P) stream; anywhere else the same values come from the plain op
+# on expanded inputs followed by torch sums.
+# The summing kernels walk the points in cell order.  Points in the order they were DRAWN are put into that order INSIDE the
+# op (round 4): with one set of points for all N tables every per-point tensor is N times smaller than the plain op's --
+# (1,C,P) cotangents and results, 64 MiB where the plain op has 1 GiB -- so sorting the points once per step
+# (cs2d_sort_points: 0.3 ms for 2^20) and carrying the cotangents into that order and the results back with index
+# selections costs a fraction of what the (N,C,P) streams, their records and the sums over n cost the plain op: BASELINE
+# configs[2] through autograd on drawn points 15.3 -> see profiles/round4_ablation.txt.  (The plain op cannot do the same:
+# its streams are per table, permuting them moves more than it saves -- DESIGN.md 4.4.)
+
+
+def sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx=None, kernel=0):
+    """How the *_sum_n functions will run this problem: 'kernels' (the summing kernels on the points as they are: in cell
+    order), 'sorted' (the same kernels, the points put into cell order inside the op) or None (plain op + sums)."""
+    if not (input.is_cuda and grid.is_cuda) or input.dim() != 4 or input.dtype != torch.float32:
+        return None
+    if isinstance(kernel, int) and (kernel & EXACT_MIXED):
+        return None
+    dim, shape, P = _problem(input, grid)
+    if grid.shape[0] != 1 or shape[0] < 2 or _channel_groups(input, dim) or _force_mode == 1:
+        return None
+    lib = _lib.load()
+    if not lib.cs2d_sum_over_n_supported(shape[0], shape[1], shape[2], shape[3], P, int(padding_mode), int(bool(align_corners))):
+        return None
+    with torch.cuda.device(input.device):
+        stream = torch.cuda.current_stream(input.device).cuda_stream
+        coherent = _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)
+    if coherent or shape[0] * P < MIN_COHERENT_SAMPLES:
+        return "kernels"
+    return None if torch.cuda.is_current_stream_capturing() and _sorted_points_of(ctx, grid) is None else "sorted"
 
 
 def sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx=None, kernel=0):
     """Will the *_sum_n functions run on the summing kernels for this problem (else: plain op + sums)?"""
-    if not (input.is_cuda and grid.is_cuda) or input.dim() != 4 or input.dtype != torch.float32:
-        return False
-    if isinstance(kernel, int) and (kernel & EXACT_MIXED):
-        return False
-    dim, shape, P = _problem(input, grid)
-    if grid.shape[0] != 1 or shape[0] < 2 or _channel_groups(input, dim) or _force_mode == 1:
-        return False
-    lib = _lib.load()
-    if not lib.cs2d_sum_over_n_supported(shape[0], shape[1], shape[2], shape[3], P, int(padding_mode), int(bool(align_corners))):
-        return False
-    with torch.cuda.device(input.device):
-        stream = torch.cuda.current_stream(input.device).cuda_stream
-        return bool(_order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream))
+    return sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx, kernel) is not None
+
+
+sum_n_sorts = 0          # how often the summed op put a point set into cell order itself (tests, diagnostics)
+
+
+def _sorted_points_of(ctx, grid):
+    ent = getattr(ctx, "_sorted_pts", None) if ctx is not None else None
+    return ent if ent is not None and ent[0].same(grid) else None
+
+
+def _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell):
+    """The summed op's points in cell order -> (grid in that order, perm, inverse perm): once per grid tensor and step
+    (kept in the step's context)."""
+    global sum_n_sorts
+    ent = _sorted_points_of(ctx, grid)
+    if ent is None:
+        P = grid.numel() // 2
+        pts_s, perm = sort_points(grid.reshape(P, 2), tuple(shape[2:]), padding_mode, align_corners, multicell)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(P, dtype=perm.dtype, device=perm.device)
+        ent = (_Held(grid), pts_s.view(grid.shape), perm, inv, [])
+        sum_n_sorts += 1
+        if ctx is not None:
+            ctx._sorted_pts = ent
+    return ent[1], ent[2], ent[3], ent[4]
+
+
+def _carry(t, index, dim, cache=None):
+    """t with its point axis `dim` taken in the order `index` (None stays None); `cache`: the step's list of cotangents
+    already carried over -- the backward stages of one graph node chain are handed the same grad_output again and again"""
+    if t is None:
+        return None
+    if cache is not None:
+        for held, dm, r in cache:
+            if dm == dim and held.same(t):
+                return r
+    r = t.index_select(dim, index)
+    if cache is not None:
+        cache.insert(0, (_Held(t), dim, r))
+        del cache[4:]
+    return r
 
 
 def _one(t, N):
@@ -927,13 +984,17 @@ def forward_sum_n(input, grid, offset, padding_mode, align_corners, kernel, mult
     dim, shape, P = _problem(input, grid)
     if grid.shape[0] != 1:
         raise RuntimeError("the summed op takes ONE set of points: grid must be (1, ..., %d), got %s" % (dim, tuple(grid.shape)))
-    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel):
+    mode = sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx, kernel)
+    if mode is None:
         return forward(input, grid, offset, padding_mode, align_corners, kernel, multicell, ctx).sum(0, keepdim=True)
+    inv = None
+    if mode == "sorted":           # the points as drawn: into cell order for the kernels, the result back into the caller's
+        grid, _, inv, _ = _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell)
     _offset_ok(offset, shape[0], input.device)
     output = torch.empty((1,) + out_shape(input, grid)[1:], dtype=input.dtype, device=input.device)
     _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P, padding_mode, align_corners,
           kernel, multicell, input.device, ctx, input, grid, offset, sum_n=True)
-    return output
+    return output if inv is None else output.index_select(-1, inv)
 
 
 def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
@@ -942,15 +1003,20 @@ def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners
     grad_output, input, grid = _al(grad_output, input, grid)
     dim, shape, P = _problem(input, grid)
     _shared(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
-    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or grad_output.dtype != torch.float32:
+    mode = sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx, kernel)
+    if mode is None or grad_output.dtype != torch.float32:
         return backward(_one(grad_output, shape[0]), input, grid, offset, padding_mode, align_corners, input_requires_grad,
                         kernel, multicell, ctx)
+    inv = None
+    if mode == "sorted":
+        grid, perm, inv, cache = _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell)
+        grad_output = _carry(grad_output, perm, -1, cache)
     _offset_ok(offset, shape[0], input.device)
     grad_grid = torch.empty_like(grid)
     grad_input = _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), None, _ptr(grad_grid)],
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=bool(input_requires_grad), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=4)
-    return grad_input, grad_grid
+    return grad_input, (grad_grid if inv is None else grad_grid.index_select(-2, inv))
 
 
 def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners, kernel, multicell,
@@ -961,10 +1027,16 @@ def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, pad
     _shared(grad_output, out_shape(input, grid), "grad_output", input.device, stream=True)
     if grad_out_grid is not None:
         _same(grad_out_grid, grid.shape, "grad_out_grid", input.device)
-    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or grad_output.dtype != torch.float32:
+    mode = sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx, kernel)
+    if mode is None or grad_output.dtype != torch.float32:
         gI, gG, ggO = backward_backward(None, grad_out_grid, input, grid, _one(grad_output, shape[0]), offset, padding_mode,
                                         align_corners, False, kernel, multicell, ctx, want_grad_input)
         return gI, gG, ggO.sum(0, keepdim=True)
+    inv = None
+    if mode == "sorted":
+        grid, perm, inv, cache = _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell)
+        grad_output = _carry(grad_output, perm, -1, cache)
+        grad_out_grid = _carry(grad_out_grid, perm, -2)
     _offset_ok(offset, shape[0], input.device)
     grad_grid = torch.empty_like(grid)
     grad_grad_out = torch.empty_like(grad_output)
@@ -973,6 +1045,8 @@ def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, pad
                         _ptr(grad_grid), _ptr(grad_grad_out)],
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=bool(want_grad_input), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=6)
+    if inv is not None:
+        grad_grid, grad_grad_out = grad_grid.index_select(-2, inv), grad_grad_out.index_select(-1, inv)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -989,10 +1063,17 @@ def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, gra
         if t is not None:
             _same(t, grid.shape, nm, input.device)
     fp32 = grad_output.dtype == torch.float32 and (grad_out_ggout is None or grad_out_ggout.dtype == torch.float32)
-    if not sum_over_n_fused(input, grid, padding_mode, align_corners, multicell, ctx, kernel) or not fp32:
+    mode = sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx, kernel)
+    if mode is None or not fp32:
         gI, ggO = bbb_fused(input, grid, _one(grad_output, shape[0]), grad_out_grid, grad_out_ggrid,
                             _one(grad_out_ggout, shape[0]), offset, padding_mode, align_corners, kernel, multicell, ctx)
         return gI, ggO.sum(0, keepdim=True)
+    inv = None
+    if mode == "sorted":
+        grid, perm, inv, cache = _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell)
+        grad_output = _carry(grad_output, perm, -1, cache)
+        grad_out_ggout = _carry(grad_out_ggout, perm, -1)
+        grad_out_grid, grad_out_ggrid = _carry(grad_out_grid, perm, -2), _carry(grad_out_ggrid, perm, -2)
     _offset_ok(offset, shape[0], input.device)
     grad_grad_out = torch.empty_like(grad_output)
     grad_input = _call("bbb_fused", dim,
@@ -1000,7 +1081,7 @@ def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, gra
                         _ptr(offset), None, _ptr(grad_grad_out)],
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=True, go_ns=0, ho_ns=0, grad_output=grad_output, sum_n=True, gi_index=7)
-    return grad_input, grad_grad_out
+    return grad_input, (grad_grad_out if inv is None else grad_grad_out.index_select(-1, inv))
 
 
 def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,

@@ -44,3 +44,55 @@ def test_summed_op_returns_the_third_order_grid_gradient_of_mixed_kernels(d, ker
     for x, y, nm in zip(a, b, ("first", "second", "third-order d/dgrid", "d/dcells")):
         assert x is not None, nm
         assert_close(x, y, "summed op vs plain op + sum: %s" % nm, 2e-5)
+
+
+def _oracle_sum_n(t, off, ke, N):
+    """the reference's way of writing the PIXEL pattern: repeat the points, expand the cotangents, sum afterwards"""
+    from oracle import cs_oracle
+    rep = lambda g: g.repeat((N,) + (1,) * (g.dim() - 1)).contiguous()
+    exp = lambda g: g.expand((N,) + tuple(g.shape[1:])).contiguous()
+    grid = rep(t["grid"])
+    r = {}
+    r["out"] = cs_oracle.forward(t["inp"], grid, off, 0, True, ke, True).sum(0, keepdim=True)
+    gI, gG = cs_oracle.backward(exp(t["gOut"]), t["inp"], grid, off, 0, True, True, ke, True)
+    r["gI"], r["gG"] = gI, gG.sum(0, keepdim=True)
+    bI, bG, bO = cs_oracle.backward_backward(None, rep(t["cG"]), t["inp"], grid, exp(t["gOut"]), off, 0, True, False, ke, True)
+    r["bbI"], r["bbG"], r["bbO"] = bI, bG.sum(0, keepdim=True), bO.sum(0, keepdim=True)
+    tI, tO = cs_oracle.bbb_fused(t["inp"], grid, exp(t["gOut"]), rep(t["cG"]), rep(t["hG"]), exp(t["hO"]), off, 0, True, ke, True)
+    r["tI"], r["tO"] = tI, tO.sum(0, keepdim=True)
+    return r
+
+
+@pytest.mark.parametrize("N,C,size,P,ke", [(4, 16, (48, 40), 30011, 0), (3, 5, (64, 64), 70001, 2), (16, 32, (16, 16), 20000, 0)])
+def test_summed_op_orders_drawn_points_inside_the_op(N, C, size, P, ke):
+    """points in the order they were drawn: the summed op sorts them once per step (ops.sum_n_sorts), runs the summing
+    kernels, and hands every per-point result back in the caller's order -- against the oracle run the reference's way"""
+    from helpers import offsets
+    g = torch.Generator().manual_seed(41 + C)
+    t = dict(inp=torch.rand((N, C) + size, generator=g), grid=torch.rand(1, 1, P, 2, generator=g) * 2.1 - 1.05,
+             gOut=torch.randn(1, C, 1, P, generator=g), hO=torch.randn(1, C, 1, P, generator=g),
+             cG=torch.randn(1, 1, P, 2, generator=g), hG=torch.randn(1, 1, P, 2, generator=g))
+    off = offsets(N, True)
+    want = _oracle_sum_n(t, off, ke, N)
+    x = {k: v.to(DEV) for k, v in t.items()}
+    o = off.to(DEV)
+    ops.points_order("random")
+    ops.force_path(2)
+    try:
+        sorts = ops.sum_n_sorts
+        sc = ops.StepContext()
+        assert ops.sum_over_n_mode(x["inp"], x["grid"], 0, True, True, sc) == "sorted"
+        got = dict(out=ops.forward_sum_n(x["inp"], x["grid"], o, 0, True, ke, True, ctx=sc))
+        got["gI"], got["gG"] = ops.backward_sum_n(x["gOut"], x["inp"], x["grid"], o, 0, True, True, ke, True, ctx=sc)
+        got["bbI"], got["bbG"], got["bbO"] = ops.backward_backward_sum_n(x["cG"], x["inp"], x["grid"], x["gOut"], o, 0, True, ke,
+                                                                           True, ctx=sc)
+        got["tI"], got["tO"] = ops.bbb_fused_sum_n(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], o, 0, True, ke,
+                                                    True, ctx=sc)
+        torch.cuda.synchronize()
+        assert ops.sum_n_sorts - sorts == 1, "one ordering of the points per step"
+    finally:
+        ops.force_path(0)
+        ops.points_order("auto")
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert_close(got[k], want[k], "summed op on drawn points: %s" % k)

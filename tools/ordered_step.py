@@ -20,9 +20,10 @@ torch.manual_seed(1)
 gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
 off = multicell_offset(N, True, dev)
-if os.environ.get("CS_CHUNKS"):
-    f, b, bb, bbb = (int(x) for x in os.environ["CS_CHUNKS"].split(","))
-    assert ops._lib.load().cs_debug_coherent_tuning(f | b << 8 | bb << 16 | bbb << 24, 0) == 1, "needs COSINESAMPLER_DEBUG=1"
+if os.environ.get("CS_CHUNKS") or os.environ.get("CS_WPB"):
+    f, b, bb, bbb = (int(x) for x in os.environ.get("CS_CHUNKS", "4,6,6,6").split(","))
+    wpb = int(os.environ.get("CS_WPB", "1"))           # waves per workgroup (1..4)
+    assert ops._lib.load().cs_debug_coherent_tuning(f | b << 8 | bb << 16 | bbb << 24, wpb << 4) == 1, "needs COSINESAMPLER_DEBUG=1"
 
 
 def step(ev=None):
@@ -58,5 +59,5 @@ for _ in range(steps):
     step(ev)
 torch.cuda.synchronize()
 st = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) for i in range(4)]
-print("chunks %-12s step %.3f ms | forward %.3f  backward %.3f  backward_backward %.3f  bbb_fused %.3f"
-      % (os.environ.get("CS_CHUNKS", "default"), ms, *st), flush=True)
+print("wpb %s chunks %-12s step %.3f ms | forward %.3f  backward %.3f  backward_backward %.3f  bbb_fused %.3f"
+      % (os.environ.get("CS_WPB", "1"), os.environ.get("CS_CHUNKS", "default"), ms, *st), flush=True)
