@@ -339,7 +339,6 @@ __device__ __forceinline__ void sum_batch3(float4 *img, uint32_t *cnt, const Bat
 template <int CQ, int MODE>
 __global__ __launch_bounds__(256) void tile3_scatter(const float *__restrict__ rows, Plan pl, float *__restrict__ out,
                                                      Dims d, int waves) {
-    constexpr int CP = 4 * CQ;
     extern __shared__ float4 img_all[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t bucket = (int64_t)blockIdx.x * waves + wv;

@@ -12,6 +12,13 @@
 namespace cs {
 namespace cl {
 
+// waves per SIMD the backward point kernels are compiled for (A/B builds).  They hold 144-184 registers (2-3 waves per
+// SIMD); asking the compiler for more waves only makes it spill: BASELINE configs[3] 3.22 ms as is, 3.31 / 3.99 / 5.26 at
+// 3 / 4 / 5 waves per SIMD (profiles/round4_ablation.txt) -- more occupancy has to come from fewer live values per lane.
+#ifndef CS_CL_WAVES
+#define CS_CL_WAVES 1
+#endif
+
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
     return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
 }
 
 template <int DIM, int KERNEL, int CQ, int SCATTER, typename ST = float>
-__global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, const float *__restrict__ icl,
+__global__ __launch_bounds__(256, CS_CL_WAVES) void backward(const ST *__restrict__ gOut, const float *__restrict__ icl,
                                                 const float *__restrict__ grid, const float *__restrict__ offset,
                                                 float *__restrict__ grad_grid, float *__restrict__ acc_cl, Dims d,
                                                 Flags f) {
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void backward(const ST *__restrict__ gOut, con
 }
 
 template <int DIM, int KERNEL, int CQ, bool HAS_CI, int SCATTER, typename ST = float>
-__global__ __launch_bounds__(256) void backward_backward(const float *__restrict__ cIcl, const float *__restrict__ cG,
+__global__ __launch_bounds__(256, CS_CL_WAVES) void backward_backward(const float *__restrict__ cIcl, const float *__restrict__ cG,
                                                          const float *__restrict__ icl, const float *__restrict__ grid,
                                                          const ST *__restrict__ gOut, const float *__restrict__ offset,
                                                          float *__restrict__ gGrid, ST *__restrict__ ggOut,
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256) void backward_backward(const float *__restrict
 }
 
 template <int DIM, int KERNEL, int CQ, int SCATTER, typename ST = float>
-__global__ __launch_bounds__(256) void bbb(const float *__restrict__ icl, const float *__restrict__ grid,
+__global__ __launch_bounds__(256, CS_CL_WAVES) void bbb(const float *__restrict__ icl, const float *__restrict__ grid,
                                            const ST *__restrict__ gOut, const float *__restrict__ cG,
                                            const float *__restrict__ hG, const ST *__restrict__ hO,
                                            const float *__restrict__ offset, ST *__restrict__ ggOut,
