@@ -17,7 +17,7 @@ import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round4"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 def newest(pattern):
     """one CSV per pass directory: gpurun merges a new run's files next to those of earlier runs"""
@@ -66,7 +66,8 @@ def total(prefixes, field):
     return t
 
 
-T = 16 * 16 * 256 * 256 * 4      # the zero-fill of one grad_input (the launches of zero_fill are not told apart by stage)
+T = 16 * 16 * 256 * 256 * 4      # the clear of the step's accumulator (round 4: ONE per step, torch's fill kernel, charged
+                                 # to the first scatter stage; the one conversion of the ordered step to the last)
 plan = ["cs::tiled::plan_count", "cs::tiled::plan_scan_chunks", "cs::tiled::plan_scan_tiles", "cs::tiled::plan_scatter",
         "cs::tiled::plan_tile_sort"]
 stages = {
@@ -75,11 +76,11 @@ stages = {
     "backward": ["cs::tiled::point_backward<0, 4, true, float>", "cs::tiled::tile_scatter<4, 0, true>"],
     "backward_backward": ["cs::tiled::point_bb<0, 4, false, 2, float>", "cs::tiled::tile_scatter<4, 2, false>"],
     "bbb_fused": ["cs::tiled::point_bbb<0, 4, true, true, float>", "cs::tiled::tile_scatter<4, 3, false>"],
-    # the headline step on ORDERED points (bench.py presorted_points): coherent kernels, no plan; each scatter stage also
-    # clears a channels-last accumulator (zero_fill, T bytes written) and unpacks it (cs::unpack_cl4)
+    # the headline step on ORDERED points (bench.py presorted_points): coherent kernels, no plan; the three scatter stages add
+    # into one channels-last accumulator: cleared once (T bytes written), unpacked once (cs::unpack_cl4) after the last stage
     "ordered_forward": ["cs::pack_cl4$", "cs::coh::stage<0, 4, 0, false, true, float, true, false>$"],
-    "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float, true, false>$", "cs::unpack_cl4"],
-    "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float, true, false>$", "cs::unpack_cl4"],
+    "ordered_backward": ["cs::coh::stage<0, 4, 1, false, true, float, true, false>$"],
+    "ordered_backward_backward": ["cs::coh::stage<0, 4, 2, false, true, float, true, false>$"],
     "ordered_bbb_fused": ["cs::coh::stage<0, 4, 3, true, true, float, true, false>$", "cs::unpack_cl4"],
     # BASELINE configs[3], same process: 3D smooth-step N=8 C=8 128^3 P=2^19 (accumulator clear not included)
     "3d_forward": ["cs::pack_cl4_zcol", "cs::cl::forward<3, 2, 2, float>"],
@@ -95,8 +96,7 @@ out = {"source": "rocprofv3 --pmc, one pass per counter group, python bench.py -
        "csrc_digest": bench.csrc_digest(),
        "bytes_per_launch": {}, "raw": {}, "by_request_size": {}}
 for st, ks in stages.items():
-    extra = T if st in ("backward", "backward_backward", "bbb_fused", "ordered_backward", "ordered_backward_backward",
-                        "ordered_bbb_fused") else 0
+    extra = T if st in ("backward", "ordered_backward") else 0
     out["bytes_per_launch"][st] = total(ks, "corrected") + extra
     out["raw"][st] = total(ks, "raw") + extra
     out["by_request_size"][st] = total(ks, "by_size") + extra

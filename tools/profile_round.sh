@@ -6,7 +6,7 @@
 # with tracing.  Each run is bounded: a profiler that hangs must not take the box with it.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-round3}
+TAG=${1:-round4}
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1 || echo "kernel-trace failed"
 echo "kernel trace done"
 i=0
