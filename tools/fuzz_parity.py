@@ -36,7 +36,7 @@ GRID_SHAPED = ("grid", "cG", "hG")
 GRID_RESULTS = ("gG", "gG0", "bbG", "bG0")
 
 
-def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
+def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False, acc=False):
     """bc: one set of points for every n.  The product (ops) is handed (1, ..., dim) tensors; the oracle, like the
     reference, the repeated ones, and its grid-shaped results are summed over n."""
     x = {k: v.to(dev) for k, v in t.items()}
@@ -49,7 +49,9 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
     off = off.to(dev)
     kw = {}
     if shared:
-        kw["ctx"] = ops.StepContext()
+        # acc (round 4): an ACCUMULATING context -- the five scatter stages below add into one step accumulator
+        # (cs_cotangent_layout.accumulate_grad_input, or the context's fallback sum) and return None for grad_input
+        kw["ctx"] = ops.StepContext(accumulate=acc)
     r = {}
     r["out"] = mod.forward(x["inp"], x["grid"], off, pad, align, ke, mc, **kw)
     r["gI"], r["gG"] = mod.backward(x["gOut"], x["inp"], x["grid"], off, pad, align, True, ke, mc, **kw)
@@ -61,6 +63,15 @@ def run(mod, t, off, pad, align, ke, mc, dev, shared, bc=False):
     r["k4I"], r["k4O"] = mod.backward_backward_backward(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], off, pad, align,
                                                         True, ke, mc, **kw)
     r["fI"], r["fO"] = mod.bbb_fused(x["inp"], x["grid"], x["gOut"], x["cG"], x["hG"], x["hO"], off, pad, align, ke, mc, **kw)
+    if acc:
+        parts = ("gI", "bbI", "bI0", "k4I", "fI")
+        if mod is cs_oracle:
+            r["accI"] = sum(r[k].double() for k in parts).float()
+        else:
+            assert all(r[k] is None for k in parts), "an accumulating context returns no grad_input"
+            r["accI"] = kw["ctx"].grad_input_sum()
+            for k in parts:
+                del r[k]
     if bc and mod is cs_oracle:
         for k in GRID_RESULTS:
             SCALE[k] = float(r[k].abs().max())     # the summands' magnitude: a sum over n may cancel (case 544 of seed 77:
@@ -117,6 +128,7 @@ for case in range(cases):
     # about it (the hint forced either way, or left to the op's own measurement); only the time may depend on either
     order = rng.choice(["drawn", "drawn", "sorted", "sorted", "half"])
     hint = rng.choice(["auto", "coherent", "random"])
+    acc = shared and rng.random() < 0.4          # round 4: the scatter stages add into one step accumulator
     if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
         continue                      # (every random draw of the case is above: case k is the same problem as in a full run)
     g = torch.Generator().manual_seed(seed * 100003 + case)
@@ -139,20 +151,20 @@ for case in range(cases):
              cG=torch.randn(grid.shape, generator=g), hG=torch.randn(grid.shape, generator=g), hO=torch.randn(osh, generator=g))
     off = multicell_offset(N, mc, "cpu")
     SCALE.clear()
-    want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc)
+    want = run(cs_oracle, t, off, pad, align, ke, mc, "cpu", False, bc, acc)
     if bc:
         want.update(run_sum_n(cs_oracle, t, off, pad, align, ke, mc, "cpu", False))
     ops.force_path(force)
     ops.points_order(hint)
     try:
-        got = run(ops, t, off, pad, align, ke, mc, DEV, shared, bc)
+        got = run(ops, t, off, pad, align, ke, mc, DEV, shared, bc, acc)
         if bc:
             got.update(run_sum_n(ops, t, off, pad, align, ke, mc, DEV, shared))
         torch.cuda.synchronize()
     finally:
         ops.force_path(0)
         ops.points_order("auto")
-    errs = {k: rel(got[k], want[k], SCALE.get(k, 0.0)) for k in want}
+    errs = {k: rel(got[k], want[k], SCALE.get(k, 0.0)) for k in want if k in got}
     if os.environ.get("FUZZ_ONLY") or os.environ.get("FUZZ_DETAIL") == str(case):
         for k in want:
             print(k, "%.3e" % errs[k], "max|ref| %.4g" % float(want[k].abs().max()), flush=True)
@@ -162,10 +174,10 @@ for case in range(cases):
     worst = max(errs, key=errs.get)
     if not all(torch.isfinite(v).all() for v in got.values()) or errs[worst] > 1e-5:
         bad += 1
-        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s bc=%s order=%s hint=%s -> %s %.3e"
-              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, bc, order, hint, worst, errs[worst]), flush=True)
+        print("FAIL case %d: d=%d N=%d C=%d sp=%s P=%d pad=%d align=%s kernel=%d mc=%s force=%d shared=%s bc=%s order=%s hint=%s acc=%s -> %s %.3e"
+              % (case, d, N, C, sp, P, pad, align, ke, mc, force, shared, bc, order, hint, acc, worst, errs[worst]), flush=True)
     elif case % 25 == 0:
-        print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d %s/%s) worst %s %.1e" % (case, d, C, sp, P, force, order, hint, worst, errs[worst]),
-              flush=True)
+        print("ok   case %d (d=%d C=%d sp=%s P=%d force=%d %s/%s%s) worst %s %.1e" % (case, d, C, sp, P, force, order, hint,
+                                                                                 " acc" if acc else "", worst, errs[worst]), flush=True)
 print("%d cases, %d failures" % (cases, bad))
 sys.exit(1 if bad else 0)
