@@ -1224,6 +1224,10 @@ int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, i
     return cs::sort::sort_points(3, points, P, D, H, W, padding_mode, align_corners, multicell, sorted_points, perm,
                                  workspace, workspace_bytes, (hipStream_t)stream);
 }
+int cs_carry_points(const float *in, float *out, const int32_t *index, int64_t rows, int64_t P, int width, void *stream) {
+    const int rc = cs::sort::carry_points(in, out, index, rows, P, width, (hipStream_t)stream);
+    return rc < 0 ? CS_ERR_INVALID : rc;
+}
 int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
                            int padding_mode, int align_corners, int multicell, void *stream) {
     return cs::sort::count_tile_changes(dim, points, P, D, H, W, padding_mode, align_corners, multicell, count,

@@ -54,6 +54,16 @@ __global__ __launch_bounds__(256) void gather_points(const float *__restrict__ p
     const int64_t s = perm[p];
     for (int j = 0; j < dim; ++j) out[p * dim + j] = pts[s * dim + j];
 }
+// out[r][j][k] = in[r][index[j]][k]: `rows` arrays of P elements of `width` floats each taken in the order `index` (a
+// permutation of the P points, or its inverse).  grid (ceil(P / 256), rows): consecutive workgroups share a row, so the
+// random 4-byte reads stay inside one 4 MiB row at a time (the XCD's L2) while the writes are coalesced.
+__global__ __launch_bounds__(256) void carry_rows(const float *__restrict__ in, const int32_t *__restrict__ index, int64_t P,
+                                                  int width, float *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    const int64_t row = (int64_t)blockIdx.y * P, s = index[j];
+    for (int k = 0; k < width; ++k) out[(row + j) * width + k] = in[(row + s) * width + k];
+}
 __global__ void zero_word(uint32_t *w) { *w = 0; }
 // one counter update per workgroup (with an unordered set every wave has changes: one atomic per wave on the one word
 // took 107 us for 2^20 points; per workgroup it is ~5 us)
@@ -149,6 +159,15 @@ int sort_points(int dim, const float *points, int64_t P, int64_t D, int64_t H, i
     if (e != hipSuccess) return (int)e;
     gather_points<<<nb, 256, 0, stream>>>(points, perm, P, dim, sorted_points);
     e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int carry_points(const float *in, float *out, const int32_t *index, int64_t rows, int64_t P, int width, hipStream_t stream) {
+    if (rows < 0 || P < 0 || width < 1 || width > 4 || rows > 65535 || (P + 255) / 256 > (int64_t)INT32_MAX) return -1;
+    if (rows == 0 || P == 0) return 0;
+    if (!in || !out || !index) return -1;
+    carry_rows<<<dim3((unsigned)((P + 255) / 256), (unsigned)rows), 256, 0, stream>>>(in, index, P, width, out);
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 

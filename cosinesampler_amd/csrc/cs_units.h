@@ -43,6 +43,8 @@ size_t workspace_bytes(int64_t P);
 int sort_points(int dim, const float *points, int64_t P, int64_t D, int64_t H, int64_t W, int padding_mode,
                 int align_corners, int multicell, float *sorted_points, int32_t *perm, void *workspace,
                 size_t workspace_bytes, hipStream_t stream);
+// out[r][j] = in[r][index[j]] for `rows` arrays of P elements of `width` floats (cs_carry_points)
+int carry_points(const float *in, float *out, const int32_t *index, int64_t rows, int64_t P, int width, hipStream_t stream);
 // fraction-of-coherence measure: number of times the tile of consecutive points changes, per table 0
 int count_tile_changes(int dim, const float *points, int64_t P, int64_t D, int64_t H, int64_t W, int padding_mode,
                        int align_corners, int multicell, uint32_t *count /* device, one word */, hipStream_t stream);

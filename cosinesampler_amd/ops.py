@@ -942,11 +942,35 @@ def _sum_n_order(ctx, grid, shape, padding_mode, align_corners, multicell):
         pts_s, perm = sort_points(grid.reshape(P, 2), tuple(shape[2:]), padding_mode, align_corners, multicell)
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(P, dtype=perm.dtype, device=perm.device)
+        perm, inv = perm.int(), inv.int()          # (cs_carry_points takes 32-bit indices)
         ent = (_Held(grid), pts_s.view(grid.shape), perm, inv, [])
         sum_n_sorts += 1
         if ctx is not None:
             ctx._sorted_pts = ent
     return ent[1], ent[2], ent[3], ent[4]
+
+
+def _carry_points(t, index, dim):
+    """t (an fp32 CUDA tensor) with its point axis `dim` (-1: a (.., C, .., P) stream; -2: a (.., P, d) grid-shaped tensor)
+    taken in the order `index` (int32): cs_carry_points -- rows of 4 MiB gathered one after the other, a third of the time
+    of torch.index_select (91 us per call in the Helmholtz step: profiles/round4_ablation.txt)"""
+    width = 1 if dim == -1 else int(t.shape[-1])
+    P = int(t.shape[dim])
+    if t.dtype != torch.float32 or not t.is_contiguous() or width > 4 or t.numel() != (t.numel() // (P * width)) * P * width \
+            or (dim == -1 and t.stride(-1) != 1):
+        return t.index_select(dim, index.long())
+    rows = t.numel() // (P * width)
+    # every axis between the rows and the point axis must be 1 (streams are (N,C,1,..,P), grid-shaped (N,1,..,P,d))
+    lead = 1
+    for sz in t.shape[:dim]:
+        lead *= int(sz)
+    if lead != rows:
+        return t.index_select(dim, index.long())
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().cs_carry_points(t.data_ptr(), out.data_ptr(), index.data_ptr(), rows, P, width,
+                                               torch.cuda.current_stream(t.device).cuda_stream), "cs_carry_points")
+    return out
 
 
 def _carry(t, index, dim, cache=None):
@@ -958,7 +982,7 @@ def _carry(t, index, dim, cache=None):
         for held, dm, r in cache:
             if dm == dim and held.same(t):
                 return r
-    r = t.index_select(dim, index)
+    r = _carry_points(t, index, dim)
     if cache is not None:
         cache.insert(0, (_Held(t), dim, r))
         del cache[4:]
@@ -994,7 +1018,7 @@ def forward_sum_n(input, grid, offset, padding_mode, align_corners, kernel, mult
     output = torch.empty((1,) + out_shape(input, grid)[1:], dtype=input.dtype, device=input.device)
     _call("forward", dim, [_ptr(input), _ptr(grid), _ptr(offset), _ptr(output)], shape, P, padding_mode, align_corners,
           kernel, multicell, input.device, ctx, input, grid, offset, sum_n=True)
-    return output if inv is None else output.index_select(-1, inv)
+    return output if inv is None else _carry_points(output, inv, -1)
 
 
 def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners, input_requires_grad, kernel, multicell,
@@ -1016,7 +1040,7 @@ def backward_sum_n(grad_output, input, grid, offset, padding_mode, align_corners
     grad_input = _call("backward", dim, [_ptr(grad_output), _ptr(input), _ptr(grid), _ptr(offset), None, _ptr(grad_grid)],
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=bool(input_requires_grad), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=4)
-    return grad_input, (grad_grid if inv is None else grad_grid.index_select(-2, inv))
+    return grad_input, (grad_grid if inv is None else _carry_points(grad_grid, inv, -2))
 
 
 def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, padding_mode, align_corners, kernel, multicell,
@@ -1046,7 +1070,7 @@ def backward_backward_sum_n(grad_out_grid, input, grid, grad_output, offset, pad
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=bool(want_grad_input), go_ns=0, grad_output=grad_output, sum_n=True, gi_index=6)
     if inv is not None:
-        grad_grid, grad_grad_out = grad_grid.index_select(-2, inv), grad_grad_out.index_select(-1, inv)
+        grad_grid, grad_grad_out = _carry_points(grad_grid, inv, -2), _carry_points(grad_grad_out, inv, -1)
     return grad_input, grad_grid, grad_grad_out
 
 
@@ -1081,7 +1105,7 @@ def bbb_fused_sum_n(input, grid, grad_output, grad_out_grid, grad_out_ggrid, gra
                         _ptr(offset), None, _ptr(grad_grad_out)],
                        shape, P, padding_mode, align_corners, kernel, multicell, input.device, ctx, input, grid, offset,
                        want_grad_input=True, go_ns=0, ho_ns=0, grad_output=grad_output, sum_n=True, gi_index=7)
-    return grad_input, (grad_grad_out if inv is None else grad_grad_out.index_select(-1, inv))
+    return grad_input, (grad_grad_out if inv is None else _carry_points(grad_grad_out, inv, -1))
 
 
 def bbb_grid(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_ggout, offset, padding_mode,

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 13
+#define CS_ABI_VERSION 14
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -231,6 +231,11 @@ int cs3d_sort_points(const float *points, float *sorted_points, int32_t *perm, i
                      void *stream);
 int cs_points_tile_changes(int dim, const float *points, uint32_t *count, int64_t P, int64_t D, int64_t H, int64_t W,
                            int padding_mode, int align_corners, int multicell, void *stream);
+/* Per-point data carried along with a permutation of the points: out[r][j][k] = in[r][index[j]][k] for `rows` arrays of P
+ * elements of `width` (1..4) floats -- a (C,P) stream has rows = C, width = 1; a [P,2] grid-shaped tensor rows = 1,
+ * width = 2.  `index` = the perm of cs2d_sort_points (into cell order) or its inverse (back).  How the summed op
+ * (CS_SUM_OVER_N) serves points in the order they were drawn: its per-point tensors are N times smaller than the plain op's. */
+int cs_carry_points(const float *in, float *out, const int32_t *index, int64_t rows, int64_t P, int width, void *stream);
 /* The same count taken on a SAMPLE: `segments` (1..65536) runs of 1024 consecutive points spread evenly over the set (all
  * of it when P <= 1024 * segments) -- a few microseconds whatever P is, and unlike a prefix it sees every part of the set.
  * The hint pays when changes * 256 <= min(P, 1024 * segments). */
