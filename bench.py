@@ -177,17 +177,20 @@ def helmholtz_step(N, C, H, P, dev, steps=3, broadcast_grid=False, sort_points=F
     return e0.elapsed_time(e1) / steps
 
 
-def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None, warm_plan=False, sort_points=False):
+def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=None, warm_plan=False, sort_points=False,
+                      summed=False):
     """forward + the three backward stages on synthetic inputs of the given shape (any of BASELINE.json's configs or
-    the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step)."""
+    the reference test scripts' shapes), fresh StepContext per step -> (ms per step, samples per step).
+    summed: the PIXEL pattern as ONE op (CS_SUM_OVER_N: one set of points and cotangents, per-point results summed over
+    the tables) -- the same table samples, the same input-shaped gradients, 1/N of the streams."""
     from cosinesampler_amd import multicell_offset, ops
     g = torch.Generator(device="cpu").manual_seed(11)
     cells = torch.rand((N, C) + (size,) * dim, generator=g).to(dev)
     pts = (torch.rand(P, dim, generator=g) * 2 - 1).to(dev)
     if sort_points:          # a fixed point set ordered once by cell (ops.sort_points), as in the 2D headline's presorted_points
         pts, _ = ops.sort_points(pts, (size,) * dim)
-    grid = pts.view((1,) * dim + (P, dim)).repeat((N,) + (1,) * (dim + 1)).contiguous()
-    oshape = (N, C) + (1,) * (dim - 1) + (P,)
+    grid = pts.view((1,) * dim + (P, dim)).repeat((1 if summed else N,) + (1,) * (dim + 1)).contiguous()
+    oshape = (1 if summed else N, C) + (1,) * (dim - 1) + (P,)
     gOut = torch.randn(oshape, generator=g).to(dev)
     hO = torch.randn(oshape, generator=g).to(dev)
     if stream_dtype is not None:     # the channel-major streams in float16 / bfloat16, read and written natively
@@ -198,6 +201,12 @@ def stage_pipeline_ms(dev, dim, N, C, size, P, kernel, steps=10, stream_dtype=No
 
     def one():
         sc = ops.StepContext()
+        if summed:
+            ops.forward_sum_n(cells, grid, off, 0, True, kernel, True, ctx=sc)
+            ops.backward_sum_n(gOut, cells, grid, off, 0, True, True, kernel, True, ctx=sc)
+            ops.backward_backward_sum_n(cG, cells, grid, gOut, off, 0, True, kernel, True, ctx=sc)
+            ops.bbb_fused_sum_n(cells, grid, gOut, cG, hG, hO, off, 0, True, kernel, True, ctx=sc)
+            return
         ops.forward(cells, grid, off, 0, True, kernel, True, ctx=sc, out_dtype=stream_dtype)
         ops.backward(gOut, cells, grid, off, 0, True, True, kernel, True, ctx=sc)
         ops.backward_backward(None, cG, cells, grid, gOut, off, 0, True, False, kernel, True, ctx=sc)
@@ -518,6 +527,10 @@ def main():
                     # neighbouring samples share lines
                     line[key]["ms_per_step_sorted_points"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, sort_points=True)[0]
                     line[key]["ms_per_step_sorted_points_warm_plan"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, warm_plan=True, sort_points=True)[0]
+                    # the config's points are the same for every table (PIXEL): as ONE summed op (CS_SUM_OVER_N in 3D,
+                    # round 4) -- the same table samples and input-shaped gradients, one set of (1,C,P) streams
+                    line[key]["ms_per_step_summed_op"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, summed=True)[0]
+                    line[key]["ms_per_step_summed_op_sorted_points"] = stage_pipeline_ms(dev, dim_, n_, c_, size_, p_, kern_, summed=True, sort_points=True)[0]
             ms_h, s_h = stage_pipeline_ms(dev, 2, N, C, H, P, 0, stream_dtype=torch.bfloat16)
             line["bf16_streams"] = {"ms_per_step": ms_h, "Msamples_per_s": s_h / ms_h / 1e3,
                                     "what": "the headline step with output / grad_output / grad_grad_out / grad_out_ggout "

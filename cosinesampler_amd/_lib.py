@@ -33,10 +33,10 @@ EXPORTS = (["cs_abi_version", "cs_error_string", "cs_workspace_bytes", "cs_half_
             "cs2d_plan_bytes", "cs2d_plan_build", "cs3d_plan_bytes", "cs3d_plan_build", "cs_debug_force_path",
             "cs2d_plan_keeps_sorted_copy", "cs_sort_points_bytes", "cs2d_sort_points", "cs3d_sort_points",
             "cs_points_tile_changes", "cs_points_tile_changes_sampled", "cs_debug_coherent_tuning", "cs2d_sum_over_n_supported",
-            "cs_accumulator_kind", "cs_accumulator_bytes", "cs_accumulator_finish", "cs_carry_points"]
+            "cs_accumulator_kind", "cs_accumulator_bytes", "cs_accumulator_finish", "cs_carry_points", "cs_sum_over_n_supported"]
            + ["cs%dd_%s" % (d, s) for d in (2, 3) for s in _STAGES] + ["cs2d_bbb_grid", "cs3d_bbb_grid"])
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 ERR_UNSUPPORTED = -2       # CS_ERR_UNSUPPORTED
 STAGE_NO_GRAD_INPUT = 0x10   # CS_STAGE_NO_GRAD_INPUT
 STREAM_F16, STREAM_BF16 = 0x1000, 0x2000   # CS_STREAM_F16 / CS_STREAM_BF16, OR-ed into `kernel`
@@ -102,6 +102,8 @@ def load():
     lib.cs_points_tile_changes_sampled.argtypes = [_c_int, _c_f, _c_f] + [_c_i64] * 4 + [_c_int] * 4 + [_c_f]
     lib.cs_debug_coherent_tuning.restype = _c_int
     lib.cs_debug_coherent_tuning.argtypes = [_c_int, _c_int]
+    lib.cs_sum_over_n_supported.restype = _c_int
+    lib.cs_sum_over_n_supported.argtypes = [_c_int] + [_c_i64] * 6 + [_c_int] * 2
     lib.cs_carry_points.restype = _c_int
     lib.cs_carry_points.argtypes = [_c_f, _c_f, _c_f, _c_i64, _c_i64, _c_int, _c_f]
     lib.cs_accumulator_kind.restype = _c_int

@@ -76,6 +76,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.d.tab_cs = pb.d.vol;
     pb.d.go_ns = pb.d.ho_ns = pb.d.out_ns = C * P;   // contiguous streams unless the entry point is given a layout
     pb.d.grid_ns = grid_bc ? 0 : P;
+    pb.d.nsum = 0;            // set by use_nsum3() where a 3D stage runs in the summing mode
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
@@ -734,6 +735,29 @@ bool rows_cl_applies(int dim, int64_t N, int64_t C, int64_t P, int64_t vol) {
     return mode >= 2 || N * P >= (1 << 16);   // (global node ids of the fused scatter are 32-bit)
 }
 
+// CS_SUM_OVER_N in 3D (round 4): the channels-last point kernels walk the N tables per point (cs_points_cl.cuh, Walk).
+// One lane per POINT: the launch covers P, the streams have no n.  fp32 streams, like the 2D summing kernels.
+bool sum_n3_applies(const Problem &pb) {
+    return pb.sum_n && pb.dim == 3 && pb.sdt == 0 && pb.d.grid_ns == 0 && pb.d.N > 1 && pb.d.S > 0 && pb.d.C > 0 &&
+           rows_cl_applies(3, pb.d.N, pb.d.C, pb.d.P, pb.d.vol);
+}
+// the problem as the summing launch sees it; the scatter kernels that follow get the plain one (their work is per table)
+Problem nsum3(const Problem &pb) {
+    Problem q = pb;
+    if (sum_n3_applies(pb)) {
+        q.d.nsum = 1;
+        q.blocks = (unsigned)((pb.d.P + kBlock - 1) / kBlock);
+    }
+    return q;
+}
+int sum_n3_check(const Problem &pb, bool has_gO, bool has_hO) {
+    if (!pb.sum_n) return CS_OK;
+    if (!sum_n3_applies(pb)) return CS_ERR_UNSUPPORTED;
+    if ((has_gO && pb.d.go_ns != 0) || (has_hO && pb.d.ho_ns != 0)) return CS_ERR_INVALID;      // one cotangent for every table
+    return CS_OK;
+}
+
+
 // 3D crowded tables (cs_dense3d.cuh): cells fit the LDS histogram, one (node, channel) value per lane in cell_scatter3
 // (two at 16 channels), and enough samples per cell for a wave per cell to pay: measured with 32^3-cell tables, 28 samples per cell
 // 1.9 vs 4.9 ms per stage, 2.8 per cell 1.47 vs 1.26 ms -- the threshold is 8
@@ -923,10 +947,13 @@ int rcl_forward(const Problem &pb, const float *input, const float *grid, const 
                 const float *input_cl, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
-    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    int rc = sum_n3_check(pb, false, false);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::forward<DIM, KERNEL, CQ, ST><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                      icl, grid, offset, (ST *)output, pb.d, pb.f))));
+    rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    const Problem pk = nsum3(pb);      // (the summing mode: one lane per point, walking the tables)
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::forward<DIM, KERNEL, CQ, ST><<<pk.blocks, kBlock, 0, pb.stream>>>(
+                                      icl, grid, offset, (ST *)output, pk.d, pb.f))));
     return launch_status();
 }
 
@@ -1011,11 +1038,14 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
                  size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
-    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    int rc = sum_n3_check(pb, true, false);
     if (rc) return rc;
+    rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    const Problem pk = nsum3(pb);
     if (!grad_input) {
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 0, ST><<<pb.blocks, kBlock, 0, pb.stream>>>(
-                                          (const ST *)gOut, icl, grid, offset, grad_grid, nullptr, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 0, ST><<<pk.blocks, kBlock, 0, pb.stream>>>(
+                                          (const ST *)gOut, icl, grid, offset, grad_grid, nullptr, pk.d, pb.f))));
         return launch_status();
     }
     const size_t shm = rcl_lds<DIM>(pb.d.C, 0);
@@ -1027,8 +1057,8 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
         if (rc) return rc;
         if (way == 1) rc = zero_async(grad_input, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                          (const ST *)gOut, icl, grid, offset, grad_grid, rows, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 2, ST><<<pk.blocks, kBlock, shm, pb.stream>>>(
+                                          (const ST *)gOut, icl, grid, offset, grad_grid, rows, pk.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return way == 1 ? dense3_scatter<0>(pb, pl, rows, grad_input) : tiles3_scatter<0>(pb, pl, rows, grad_input);
@@ -1036,8 +1066,8 @@ int rcl_backward(const Problem &pb, const float *gOut, const float *input, const
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 1, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      (const ST *)gOut, icl, grid, offset, grad_grid, acc, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward<DIM, KERNEL, CQ, 1, ST><<<pk.blocks, kBlock, shm, pb.stream>>>(
+                                      (const ST *)gOut, icl, grid, offset, grad_grid, acc, pk.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     return rcl_finish(pb, acc, grad_input);
@@ -1049,8 +1079,12 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
            const void *plan, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
-    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (pb.sum_n && cI) return CS_ERR_UNSUPPORTED;       // (the summed op has no cotangent of grad_input: not the PIXEL pattern)
+    int rc = sum_n3_check(pb, true, false);
     if (rc) return rc;
+    rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    const Problem pk = nsum3(pb);
     const float *cIcl = nullptr;
     if (cI) {
         float *buf = (float *)ws.take(table_floats(DIM, pb.d.N, pb.d.C, pb.d.vol) * 4);
@@ -1078,7 +1112,7 @@ int rcl_bb(const Problem &pb, const float *cI, const float *cG, const float *inp
     const size_t shm = gInput ? rcl_lds<DIM>(pb.d.C, 1) : 0;
 #define CS_RCL_BB(HAS_CI, SCATTER)                                                                                   \
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::backward_backward<DIM, KERNEL, CQ, HAS_CI, SCATTER, ST>  \
-                                      <<<pb.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, (const ST *)gOut, offset, gGrid, (ST *)ggOut, acc, pb.d, pb.f))))
+                                      <<<pk.blocks, kBlock, shm, pb.stream>>>(cIcl, cG, icl, grid, (const ST *)gOut, offset, gGrid, (ST *)ggOut, acc, pk.d, pb.f))))
     if (cIcl && dense) { CS_RCL_BB(true, 2); }
     else if (cIcl && gInput) { CS_RCL_BB(true, 1); }
     else if (cIcl) { CS_RCL_BB(true, 0); }
@@ -1099,8 +1133,11 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
             const float *input_cl, const void *plan, void *workspace, size_t workspace_bytes) {
     Carve ws{(char *)workspace, 0, workspace ? workspace_bytes : 0};
     const float *icl;
-    int rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    int rc = sum_n3_check(pb, true, hO != nullptr);
     if (rc) return rc;
+    rc = rows_cl_table(pb, input, input_cl, ws, icl);
+    if (rc) return rc;
+    const Problem pk = nsum3(pb);
     const size_t shm = rcl_lds<DIM>(pb.d.C, 2);
     if (const int way = scatter3_way<DIM>(pb)) {
         tl::Plan pl;
@@ -1110,8 +1147,8 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
         if (rc) return rc;
         if (way == 1) rc = zero_async(gInput, (int64_t)pb.d.N * pb.d.C * pb.d.vol, pb.stream);
         if (rc) return rc;
-        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                          icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, rows, pb.d, pb.f))));
+        CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 2, ST><<<pk.blocks, kBlock, shm, pb.stream>>>(
+                                          icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, rows, pk.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         return way == 1 ? dense3_scatter<2>(pb, pl, rows, gInput) : tiles3_scatter<2>(pb, pl, rows, gInput);
@@ -1119,8 +1156,8 @@ int rcl_bbb(const Problem &pb, const float *input, const float *grid, const floa
     float *acc;
     rc = rcl_accumulator(pb, ws, acc);
     if (rc) return rc;
-    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 1, ST><<<pb.blocks, kBlock, shm, pb.stream>>>(
-                                      icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, acc, pb.d, pb.f))));
+    CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQ(pb.d.C, (cs::cl::bbb<DIM, KERNEL, CQ, 1, ST><<<pk.blocks, kBlock, shm, pb.stream>>>(
+                                      icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, (ST *)ggOut, acc, pk.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     return rcl_finish(pb, acc, gInput);
@@ -1280,6 +1317,15 @@ int cs2d_sum_over_n_supported(int64_t N, int64_t C, int64_t H, int64_t W, int64_
     return cs::coh::supported_nsum(coh_launch(pb)) ? 1 : 0;
 }
 
+int cs_sum_over_n_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode,
+                            int align_corners) {
+    if (dim == 2) return cs2d_sum_over_n_supported(N, C, H, W, P, padding_mode, align_corners);
+    if (dim != 3 || N <= 1 || C <= 0 || P <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    Problem pb;
+    if (make_problem(pb, 3, N, C, D, H, W, P, padding_mode, align_corners, CS_GRID_BROADCAST | CS_SUM_OVER_N, 1, nullptr)) return 0;
+    return sum_n3_applies(pb) ? 1 : 0;
+}
+
 size_t cs_pack_bytes(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P) {
     if (N <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
     const int64_t vol = (dim == 3 ? D : 1) * H * W;
@@ -1349,7 +1395,7 @@ int cs3d_plan_build(const float *grid, const float *offset, void *plan, size_t p
         if (rc_) return rc_;                                                                                      \
     }                                                                                                             \
     const bool tiled = pb.d.S > 0 && pb.d.C > 0 && tiled_applies(dim, N, C, H, W, P);                             \
-    if (pb.sum_n && !tiled) return CS_ERR_UNSUPPORTED;                                                            \
+    if (pb.sum_n && !tiled && !(dim == 3 && sum_n3_applies(pb))) return CS_ERR_UNSUPPORTED;                       \
     bool g_sorted = false, g_leave = false;                                                                       \
     (void)g_sorted; (void)g_leave;                                                                                \
     const bool rows = !tiled && pb.d.S > 0 && pb.d.C > 0 && rows_applies(N, C, P, pb.d.vol);                      \

@@ -35,6 +35,9 @@ struct Dims {
     // points between consecutive n of grid, grad_out_grid and grad_out_ggrid: P, or 0 when ONE set of P points serves
     // every n (CS_GRID_BROADCAST: PIXEL's grid.repeat(N, ...), test/test_2d.py:38, without the repeat)
     int64_t grid_ns;
+    // CS_SUM_OVER_N on the channels-last point kernels (cs_points_cl.cuh, 3D): non-zero = one lane owns a POINT for all N
+    // tables and the per-point results leave summed over them (the streams then have no n: go_ns = ho_ns = grid_ns = 0)
+    int nsum;
     __host__ __device__ __forceinline__ int64_t gpt(int n, int64_t p) const { return (int64_t)n * grid_ns + p; }
 };
 

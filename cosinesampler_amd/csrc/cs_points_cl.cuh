@@ -107,16 +107,38 @@ __device__ __forceinline__ void scatter_phase(const float *stage, float *__restr
     }
 }
 
+// ---- the summing mode (Dims::nsum; CS_SUM_OVER_N in 3D, round 4) -------------------------------------------------
+// The PIXEL pattern sampler(cells, grid.repeat(N,..)).sum(0) (reference test/test_3d.py:31-32): ONE set of points and of
+// cotangents for all N tables, per-point results summed over the tables.  A lane owns a point and walks the tables
+// (`Walk`): the gathers of a 3D table are random HBM lines whichever table they come from, so walking the tables costs
+// nothing in locality, and the (N,C,P) streams of the plain op, their sums over n and the expanded cotangents disappear.
+// The records for the scatter stay per (table, point): the scatter kernels are the plain op's.
+struct Walk {
+    int64_t t;       // the lane's index: a sample (plain) or a point (nsum)
+    int iters;       // tables this lane walks: N (nsum) or 1
+    __device__ __forceinline__ Walk(const Dims &d) : t((int64_t)blockIdx.x * blockDim.x + threadIdx.x), iters(d.nsum ? d.N : 1) {}
+    // the sample of iteration `it` (past the end: no sample)
+    __device__ __forceinline__ int64_t sample(const Dims &d, int it) const {
+        return d.nsum ? (t < d.P ? (int64_t)it * d.P + t : d.S) : t;
+    }
+    // first sample of this lane's wave in iteration `it`, and how many of its 64 exist
+    __device__ __forceinline__ int64_t wave_first(const Dims &d, int it) const {
+        return (d.nsum ? (int64_t)it * d.P : 0) + (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+    }
+    __device__ __forceinline__ int wave_live(const Dims &d) const {
+        const int64_t lim = d.nsum ? d.P : d.S, w0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+        return w0 >= lim ? 0 : (int)(lim - w0 < 64 ? lim - w0 : 64);
+    }
+};
+
 // SCATTER == 2 (crowded tables, cs_dense3d.cuh): instead of adding them, the wave's records -- payloads and
 // coefficients, without the node ids -- go to HBM as p-ordered rows of Rec::IDS floats for cell_scatter3.
 template <int DIM, int CQ, int MODE>
-__device__ __forceinline__ void flush_records(const float *stage, float *__restrict__ rows, const Dims &d) {
+__device__ __forceinline__ void flush_records(const float *stage, float *__restrict__ rows, const Dims &d, int64_t s0, int nlive) {
     using R = Rec<DIM, CQ, MODE>;
     constexpr int PIECES = R::IDS / 4;   // float4 per row
     const int lane = threadIdx.x & 63;
-    const int64_t s0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
-    if (s0 >= d.S) return;
-    const int nlive = (int)(d.S - s0 < 64 ? d.S - s0 : 64);
+    if (nlive <= 0) return;
     float4 *dst = reinterpret_cast<float4 *>(rows + s0 * R::IDS);
     for (int item = lane; item < nlive * PIECES; item += 64) {
         const int row = item / PIECES, piece = item - row * PIECES;
@@ -129,23 +151,33 @@ __global__ __launch_bounds__(256) void forward(const float *__restrict__ icl, co
                                                const float *__restrict__ offset, ST *__restrict__ out, Dims d,
                                                Flags f) {
     constexpr int NC = 1 << DIM, C = 4 * CQ;
-    Sample<DIM> sm;
-    if (!sm.template load<KERNEL, 0>(grid, offset, d, f, DIM == 2 ? 1 : f.align)) return;
-    float W[NC];
-    sm.weights(W);
-    const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
-    const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
-    ST *o = out + (int64_t)sm.n * d.out_ns + sm.p;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count, C the padded one)
-    float4 v[CQ][NC];
+    const Walk wk(d);
+    float4 acc[CQ];
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
+    for (int q = 0; q < CQ; ++q) acc[q] = zero4();
+    int n_out = 0;
+    int64_t p_out = -1;
+    for (int it = 0; it < wk.iters; ++it) {
+        Sample<DIM> sm;
+        if (!sm.template load_at<KERNEL, 0>(wk.sample(d, it), grid, offset, d, f, DIM == 2 ? 1 : f.align)) break;
+        float W[NC];
+        sm.weights(W);
+        const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
+        const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
+        float4 v[CQ][NC];
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        float4 acc = zero4();
+        for (int q = 0; q < CQ; ++q) gather_quad<DIM, CQ>(tab, sm, q, v[q], plane);
 #pragma unroll
-        for (int a = 0; a < NC; ++a) acc = fma4(W[a], v[q][a], acc);
-        store_quad(o + (int64_t)(4 * q) * d.P, d.P, acc, d.C - 4 * q);
+        for (int q = 0; q < CQ; ++q)
+#pragma unroll
+            for (int a = 0; a < NC; ++a) acc[q] = fma4(W[a], v[q][a], acc[q]);
+        n_out = d.nsum ? 0 : sm.n;
+        p_out = sm.p;
     }
+    if (p_out < 0) return;
+    ST *o = out + (int64_t)n_out * d.out_ns + p_out;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count, C the padded one)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) store_quad(o + (int64_t)(4 * q) * d.P, d.P, acc[q], d.C - 4 * q);
 }
 
 template <int DIM, int KERNEL, int CQ, int SCATTER, typename ST = float>
@@ -158,9 +190,15 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward(const ST *__restric
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
     float *rec = stage + (threadIdx.x & 63) * R::WORDS;
+    const Walk wk(d);
+    float gsum[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) gsum[j] = 0.0f;
+    int64_t gg_out = -1;
+    for (int it = 0; it < wk.iters; ++it) {
     Sample<DIM> sm;
-    const bool live = sm.template load<KERNEL, 1>(grid, offset, d, f, f.align);
-    if (!SCATTER && !live) return;
+    const bool live = sm.template load_at<KERNEL, 1>(wk.sample(d, it), grid, offset, d, f, f.align);
+    if (!SCATTER && !live) break;
     if (SCATTER) rec_put_nodes<DIM, CQ, 0>(rec, sm, d, live);
     if (live) {
     const int64_t plane = (int64_t)d.size[0] * d.size[1];                 // 3D tables are z-paired: two rows per node
@@ -192,9 +230,9 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward(const ST *__restric
             for (int a = 0; a < NC; ++a) t = fma4(oth[j][a], v[q][a], t);
             acc[j] += dot4(t, g[q]);
         }
-    float *gg = grad_grid + ((int64_t)sm.n * d.P + sm.p) * DIM;
+    gg_out = ((int64_t)(d.nsum ? 0 : sm.n) * d.P + sm.p) * DIM;
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) gg[j] = sm.ax[j].d1 * acc[j];
+    for (int j = 0; j < DIM; ++j) gsum[j] = it == 0 ? sm.ax[j].d1 * acc[j] : fmaf(sm.ax[j].d1, acc[j], gsum[j]);
     if (SCATTER) {
         float W[NC];
         sm.weights(W);
@@ -207,7 +245,13 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward(const ST *__restric
     if (SCATTER) {
         __syncthreads();
         if (SCATTER == 1) scatter_phase<DIM, CQ, 0>(stage, acc_cl);
-        else flush_records<DIM, CQ, 0>(stage, acc_cl, d);
+        else flush_records<DIM, CQ, 0>(stage, acc_cl, d, wk.wave_first(d, it), wk.wave_live(d));
+        if (it + 1 < wk.iters) __syncthreads();           // the stage is written again for the next table
+    }
+    }
+    if (gg_out >= 0) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) grad_grid[gg_out + j] = gsum[j];
     }
 }
 
@@ -223,9 +267,19 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward_backward(const floa
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
     float *rec = stage + (threadIdx.x & 63) * R::WORDS;
+    const Walk wk(d);
+    float gsum[DIM];
+    float4 osum[CQ];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) gsum[j] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) osum[q] = zero4();
+    int n_out = 0;
+    int64_t p_out = -1;
+    for (int it = 0; it < wk.iters; ++it) {
     Sample<DIM> sm;
-    const bool live = sm.template load<KERNEL, 2>(grid, offset, d, f, f.align);
-    if (!SCATTER && !live) return;
+    const bool live = sm.template load_at<KERNEL, 2>(wk.sample(d, it), grid, offset, d, f, f.align);
+    if (!SCATTER && !live) break;
     if (SCATTER) rec_put_nodes<DIM, CQ, 1>(rec, sm, d, live);
     if (live) {
     // loads first, all of them (see bbb): grad_out_grid through a pointer that is valid either way, the cotangent quads, the
@@ -238,7 +292,6 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward_backward(const floa
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const float4 *ctab = reinterpret_cast<const float4 *>(cIcl + (int64_t)sm.n * d.vol * C * (DIM == 3 ? 2 : 1));
     const ST *go = gOut + (int64_t)sm.n * d.go_ns + sm.p;
-    ST *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
     float4 gq[CQ], vq[CQ][NC];   // all node rows in flight at once (see backward)
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
@@ -300,11 +353,13 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward_backward(const floa
                 }
             }
         }
-        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o, d.C - 4 * q);
+        // (the first table's value as it is: the plain op's results stay bit for bit what they were)
+        osum[q] = it == 0 ? o : make_float4(osum[q].x + o.x, osum[q].y + o.y, osum[q].z + o.z, osum[q].w + o.w);
     }
-    float *gg = gGrid + ((int64_t)sm.n * d.P + sm.p) * DIM;
+    n_out = d.nsum ? 0 : sm.n;
+    p_out = sm.p;
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) gg[j] = acc[j];
+    for (int j = 0; j < DIM; ++j) gsum[j] = it == 0 ? acc[j] : gsum[j] + acc[j];
     if (SCATTER) {
 #pragma unroll
         for (int a = 0; a < NC; ++a) rec[R::COEF + a] = Dm[a];
@@ -313,7 +368,17 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void backward_backward(const floa
     if (SCATTER) {
         __syncthreads();
         if (SCATTER == 1) scatter_phase<DIM, CQ, 1>(stage, acc_cl);
-        else flush_records<DIM, CQ, 1>(stage, acc_cl, d);
+        else flush_records<DIM, CQ, 1>(stage, acc_cl, d, wk.wave_first(d, it), wk.wave_live(d));
+        if (it + 1 < wk.iters) __syncthreads();           // the stage is written again for the next table
+    }
+    }
+    if (p_out >= 0) {
+        ST *ggo = ggOut + (int64_t)n_out * d.out_ns + p_out;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, osum[q], d.C - 4 * q);
+        float *gg = gGrid + ((int64_t)n_out * d.P + p_out) * DIM;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) gg[j] = gsum[j];
     }
 }
 
@@ -328,9 +393,16 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void bbb(const float *__restrict_
     extern __shared__ float lds[];
     float *stage = lds + (threadIdx.x >> 6) * (64 * R::WORDS);
     float *rec = stage + (threadIdx.x & 63) * R::WORDS;
+    const Walk wk(d);
+    float4 osum[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) osum[q] = zero4();
+    int n_out = 0;
+    int64_t p_out = -1;
+    for (int it = 0; it < wk.iters; ++it) {
     Sample<DIM> sm;
-    const bool live = sm.template load<KERNEL, 2>(grid, offset, d, f, f.align);
-    if (!SCATTER && !live) return;
+    const bool live = sm.template load_at<KERNEL, 2>(wk.sample(d, it), grid, offset, d, f, f.align);
+    if (!SCATTER && !live) break;
     if (SCATTER) rec_put_nodes<DIM, CQ, 2>(rec, sm, d, live);
     if (live) {
     // every load of the sample goes out before anything is computed from it: the cotangents of the grid (read through a
@@ -395,19 +467,27 @@ __global__ __launch_bounds__(256, CS_CL_WAVES) void bbb(const float *__restrict_
             rec[R::COEF + NC + a] = Dm[a];
         }
     }
-    ST *ggo = ggOut + (int64_t)sm.n * d.out_ns + sm.p;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
         float4 o = zero4();
 #pragma unroll
         for (int a = 0; a < NC; ++a) o = fma4(Em[a], v[q][a], o);
-        store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, o, d.C - 4 * q);
+        osum[q] = it == 0 ? o : make_float4(osum[q].x + o.x, osum[q].y + o.y, osum[q].z + o.z, osum[q].w + o.w);
     }
+    n_out = d.nsum ? 0 : sm.n;
+    p_out = sm.p;
     }
     if (SCATTER) {
         __syncthreads();
         if (SCATTER == 1) scatter_phase<DIM, CQ, 2>(stage, acc_cl);
-        else flush_records<DIM, CQ, 2>(stage, acc_cl, d);
+        else flush_records<DIM, CQ, 2>(stage, acc_cl, d, wk.wave_first(d, it), wk.wave_live(d));
+        if (it + 1 < wk.iters) __syncthreads();           // the stage is written again for the next table
+    }
+    }
+    if (p_out >= 0) {
+        ST *ggo = ggOut + (int64_t)n_out * d.out_ns + p_out;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) store_quad(ggo + (int64_t)(4 * q) * d.P, d.P, osum[q], d.C - 4 * q);
     }
 }
 

@@ -383,8 +383,8 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
         stream = torch.cuda.current_stream(device).cuda_stream
         # coherent points (CS_POINTS_COHERENT): the 2D fast path reads the table through on-chip windows and needs no plan
         # (sum_n: the summing kernels ARE coherent-points kernels; the caller has decided)
-        coherent = bool(sum_n or (dim == 2 and grid is not None
-                                  and _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)))
+        coherent = dim == 2 and bool(sum_n or (grid is not None and _order_is_coherent(
+            ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)))
         if sum_n:
             kernel |= _lib.SUM_OVER_N
         if coherent:
@@ -901,7 +901,7 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
 def sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx=None, kernel=0):
     """How the *_sum_n functions will run this problem: 'kernels' (the summing kernels on the points as they are: in cell
     order), 'sorted' (the same kernels, the points put into cell order inside the op) or None (plain op + sums)."""
-    if not (input.is_cuda and grid.is_cuda) or input.dim() != 4 or input.dtype != torch.float32:
+    if not (input.is_cuda and grid.is_cuda) or input.dim() not in (4, 5) or input.dtype != torch.float32:
         return None
     if isinstance(kernel, int) and (kernel & EXACT_MIXED):
         return None
@@ -909,8 +909,12 @@ def sum_over_n_mode(input, grid, padding_mode, align_corners, multicell, ctx=Non
     if grid.shape[0] != 1 or shape[0] < 2 or _channel_groups(input, dim) or _force_mode == 1:
         return None
     lib = _lib.load()
-    if not lib.cs2d_sum_over_n_supported(shape[0], shape[1], shape[2], shape[3], P, int(padding_mode), int(bool(align_corners))):
+    D = shape[2] if dim == 3 else 1
+    if not lib.cs_sum_over_n_supported(dim, shape[0], shape[1], D, shape[-2], shape[-1], P, int(padding_mode),
+                                       int(bool(align_corners))):
         return None
+    if dim == 3:          # the 3D point kernels walk the tables per point: any order of the points, nothing to sort
+        return "kernels"
     with torch.cuda.device(input.device):
         stream = torch.cuda.current_stream(input.device).cuda_stream
         coherent = _order_is_coherent(ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 14
+#define CS_ABI_VERSION 15
 
 enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_UNSUPPORTED = -2, CS_ERR_WORKSPACE = -3 };
 enum { CS_PAD_ZEROS = 0, CS_PAD_BORDER = 1, CS_PAD_REFLECTION = 2 };
@@ -96,10 +96,11 @@ enum { CS_KERNEL_COSINE = 0, CS_KERNEL_LINEAR = 1, CS_KERNEL_SMOOTHSTEP = 2 };
  * its n: the inputs `grid`, `grad_out_grid`, `grad_out_ggrid` are [P,2] and `grad_output`, `grad_out_ggout` are [C,P] (one
  * cotangent for every table: pass n-strides 0 in cs_cotangent_layout); the per-point RESULTS come back summed over the
  * tables -- `output` and `grad_grad_out` [C,P], `grad_grid` [P,2].  Input-shaped gradients stay [N,C,H,W].  Equal to the plain
- * op on repeated / expanded inputs followed by sums over n, without the N-fold streams in between.  Runs on the
- * coherent-points kernels (fast for points in cell order, correct for any); built for 2D, fp32 streams, zeros padding with
- * align_corners (cs2d_sum_over_n_supported), CS_ERR_UNSUPPORTED otherwise -- the caller then sums himself.  Workspace as
- * for CS_STAGE_POINTS_COHERENT. */
+ * op on repeated / expanded inputs followed by sums over n, without the N-fold streams in between.  2D: runs on the
+ * coherent-points kernels (fast for points in cell order, correct for any; fp32 streams, zeros padding with align_corners;
+ * workspace as for CS_STAGE_POINTS_COHERENT).  3D (round 4): the channels-last point kernels walk the tables per point, the
+ * scatter is the plain op's (plan, records, tile / cell / row-atomic scatter: workspace as for the plain call).
+ * cs_sum_over_n_supported says where; CS_ERR_UNSUPPORTED otherwise -- the caller then sums himself. */
 #define CS_SUM_OVER_N 0x10000
 /* stage ids for cs_workspace_bytes */
 enum { CS_STAGE_FORWARD = 0, CS_STAGE_BACKWARD = 1, CS_STAGE_BACKWARD_BACKWARD = 2, CS_STAGE_BBB_FUSED = 3 };
@@ -173,8 +174,12 @@ const char *cs_error_string(int code);
 size_t cs_workspace_bytes(int dim, int stage, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P,
                           int have_input_cl, int have_plan, int have_cI);
 
-/* 1 if the summing kernels of CS_SUM_OVER_N are built for this problem, else 0 (the caller sums himself). */
+/* 1 if the summing kernels of CS_SUM_OVER_N are built for this problem, else 0 (the caller sums himself).  2D: the
+ * coherent-points kernels (fp32 streams, zeros padding with align_corners).  3D (round 4): the channels-last point kernels
+ * walking the N tables per point (fast path: C <= 16, N > 1, fp32 streams; every padding mode, any order of the points). */
 int cs2d_sum_over_n_supported(int64_t N, int64_t C, int64_t H, int64_t W, int64_t P, int padding_mode, int align_corners);
+int cs_sum_over_n_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P, int padding_mode,
+                            int align_corners);
 /* 1 if this problem runs on a path whose kernels take 16-bit streams (CS_STREAM_F16 / CS_STREAM_BF16), else 0. */
 int cs_half_streams_supported(int dim, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t P);
 
