@@ -8,6 +8,7 @@ import os
 import random
 import sys
 
+os.environ.setdefault("COSINESAMPLER_DEBUG", "1")      # the sweep forces execution paths (ops.force_path): a testing knob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
