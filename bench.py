@@ -381,7 +381,7 @@ def main():
     # then run on the coherent-points kernels (CS_POINTS_COHERENT), no plan.  Reported beside the headline, never instead:
     # `value` stays the step on the points as drawn.
     presorted = None
-    if P == (1 << 20):
+    if P == (1 << 20) or os.environ.get("CS_BENCH_PRESORTED"):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         xy_s, perm = ops.sort_points(xy, (H, H), pad, align, mc)

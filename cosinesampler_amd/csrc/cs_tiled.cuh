@@ -292,10 +292,47 @@ __device__ __forceinline__ float ld_stream(const T *p) { return stream_load(p); 
 // ---- 16-bit streams (float16 / bfloat16 elements, fp32 arithmetic) --------------------------------------------
 // When the channel rows are dword aligned and P is even (Flags::pair16) they move two samples per dword, straight
 // between HBM and the wave's LDS rows (StreamRegs / store_rows16 below); otherwise element by element.
+// XCD-aware order of the point kernels' workgroups (a speed choice only: every order computes the same values).  The
+// launch is (ceil(P/256), N) workgroups; the dispatcher deals them round-robin over the 8 XCDs (MI355X_MICROARCH.md,
+// workgroup dispatch: blocks b and b + 8 share one), so in launch order all 8 XCDs work on table n at the same time and
+// every XCD pulls every table through its own L2 -- 8 x 64 MiB of fabric reads per stage at BASELINE configs[1], and a
+// table line is re-used by an eighth of the table's samples only.  With N a multiple of 8 the workgroups that share an XCD
+// take the tables n = x, x + 8, ... one after the other instead: a table passes through ONE L2, where its 32 768 lines are
+// each wanted by all 2^20 points' gathers.  (The channels-last table of one n, 4 MiB at configs[1], is as large as an L2.)
+// The backward point kernels gain 0.05 ms each at configs[1]; the forward one LOSES 0.02 (16 output rows per table: 128
+// write streams in flight instead of 16) and keeps the launch order (XCD = false).  profiles/round4_ablation.txt section 12.
+#ifndef CS_XCD_TABLES
+#define CS_XCD_TABLES 1
+#endif
+#ifndef CS_XCD_STAGGER
+#define CS_XCD_STAGGER 1
+#endif
+struct PBlk {
+    int x, n;      // which 256 points, which table
+};
+template <bool XCD = true>
+__device__ __forceinline__ PBlk pblk() {
+    PBlk b{(int)blockIdx.x, (int)blockIdx.y};
+#if CS_XCD_TABLES
+    if (XCD && (gridDim.y & 7u) == 0 && (uint64_t)gridDim.x * gridDim.y < (1ull << 31)) {
+        const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x, j = l >> 3, t = j / gridDim.x;
+        b.x = (int)(j - t * gridDim.x);
+        b.n = (int)((l & 7u) + 8u * t);
+#if CS_XCD_STAGGER
+        // ... and each of the 8 groups starts its tables an eighth of the points further on: the 8 tables in flight are then
+        // read and written at different p (their rows are a power of two apart: at equal p they meet in the same HBM channels)
+        b.x = (int)(((uint32_t)b.x + (l & 7u) * ((gridDim.x + 7u) >> 3)) % gridDim.x);
+#endif
+    }
+#endif
+    return b;
+}
 // the wave's first sample and how many of its 64 exist
-__device__ __forceinline__ int64_t wave_p0() { return (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); }
+template <bool XCD = true>
+__device__ __forceinline__ int64_t wave_p0() { return (int64_t)pblk<XCD>().x * 256 + (threadIdx.x & ~63); }
+template <bool XCD = true>
 __device__ __forceinline__ int wave_nlive(int64_t P) {
-    const int64_t r = P - wave_p0();
+    const int64_t r = P - wave_p0<XCD>();
     return r <= 0 ? 0 : (r > 64 ? 64 : (int)r);
 }
 template <typename T>
@@ -323,8 +360,9 @@ template <int KERNEL>
 __device__ __forceinline__ void point_phase1(float *rec, const float *grid, const float *offset, const Dims &d,
                                              const Flags &f, int align) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.y;
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const PBlk wb = pblk<false>();        // (the forward stage only: see pblk)
+    const int n = wb.n;
+    int64_t p = (int64_t)wb.x * 256 + threadIdx.x;
     if (p >= d.P) p = d.P - 1;
     const float off = offset[n];
     float2 g = *reinterpret_cast<const float2 *>(grid + d.gpt(n, p) * 2);
@@ -357,7 +395,7 @@ struct QuadSample {
         const int per = 64 / CQ;
         sl = sub * per + lane / CQ;
         q = lane % CQ;
-        p = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63) + sl;
+        p = wave_p0<false>() + sl;
         live = p < d.P;
         const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
 #pragma unroll
@@ -410,7 +448,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     float *rec = lds + (threadIdx.x >> 6) * REC_FLOATS;
     point_phase1<KERNEL>(rec, grid, offset, d, f, 1);   // 2D forward: align_corners = 1 (2d.cu:307-308)
     __syncthreads();
-    const int n = blockIdx.y;
+    const int n = pblk<false>().n;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
     ST *obase = out + (int64_t)n * d.out_ns;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
@@ -437,12 +475,12 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
         ot[(4 * qs.q + 3) * OUT_LD + qs.sl] = acc.w;
     }
     __syncthreads();
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = (int64_t)pblk<false>().x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if constexpr (sizeof(ST) == 2) if (f.pair16) {   // lanes 0..31: channel c, lanes 32..63: channel c+1 (store_rows16)
         const int L = lane & 31, up = lane >> 5;
-        if (2 * L >= wave_nlive(d.P)) return;
-        ST *row = obase + wave_p0() + 2 * L;
+        if (2 * L >= wave_nlive<false>(d.P)) return;
+        ST *row = obase + wave_p0<false>() + 2 * L;
 #pragma unroll
         for (int c0 = 0; c0 < C; c0 += 2) {
             const int c = c0 + up;
@@ -474,8 +512,9 @@ struct Sample2 {
     // stream loads in between, so that one memory round trip covers both (a wave used to wait for its coordinates,
     // work out the geometry and only then ask for the streams).
     __device__ __forceinline__ void begin(const float *grid, const Dims &d) {
-        n = blockIdx.y;
-        int64_t pp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const PBlk wb = pblk();
+        n = wb.n;
+        int64_t pp = (int64_t)wb.x * blockDim.x + threadIdx.x;
         live = pp < d.P;
         p = live ? pp : d.P - 1;
         s = (int64_t)n * d.P + p;
@@ -627,7 +666,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *uniform_
 template <int STRIDE>
 __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n, const Dims &d) {
     const int lane = threadIdx.x & 63;
-    const int64_t p0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first point of this wave
+    const int64_t p0 = wave_p0();     // first point of this wave
     if (p0 >= d.P) return;
     const int nlive = (int)min((int64_t)64, d.P - p0);
     const __amdgpu_buffer_rsrc_t dst = rows_rsrc(fat + ((int64_t)n * d.P + p0) * STRIDE);

@@ -141,6 +141,27 @@ def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
                      % (C, ke, pad, align, mc, shared, k))
 
 
+@pytest.mark.parametrize("N,C,P,sp,crowded", [(8, 16, 3001, (37, 50), False), (16, 4, 1029, (20, 33), False), (24, 8, 700, (18, 18), False),
+                                               (8, 4, 20000, (9, 12), True), (16, 16, 255, (37, 50), False)])
+def test_xcd_aware_workgroup_order_of_the_point_kernels(N, C, P, sp, crowded):
+    """With N a multiple of 8 the tiled point kernels (backward stages) take their workgroups in another order -- the 8 groups of
+    workgroups that share an XCD own the tables n = x, x + 8, .., each group starting at its own p (cs_tiled.cuh pblk): a speed
+    choice that must not change a value.  Ragged P (a last workgroup with few points, fewer workgroups than XCDs), the tile
+    walkers and the crowded-table path, every stage against the oracle."""
+    ke, pad, align, mc = 0, 0, True, True
+    t = _case(2, N, C, sp, P, seed=8800 + N + C, spread=1.1)
+    off = offsets(N, mc)
+    want = _run_all_stages(cs_oracle, t, off, pad, align, ke, mc, "cpu")
+    ops.force_path(2)
+    try:
+        got = _run_all_stages(_Shared(), t, off, pad, align, ke, mc, DEV)
+        torch.cuda.synchronize()
+    finally:
+        ops.force_path(0)
+    for k in want:
+        assert_close(got[k], want[k], "N=%d C=%d P=%d (XCD-aware order): %s" % (N, C, P, k))
+
+
 ROW_CASES = [(3, 8, 0, 0, True, True), (3, 8, 2, 0, True, True), (3, 2, 1, 1, False, False), (3, 16, 2, 2, True, False),
              (3, 4, 0, 2, False, True), (2, 2, 0, 0, True, True), (2, 32, 2, 1, True, False), (2, 64, 1, 0, False, False),
              (3, 3, 0, 0, True, True), (3, 1, 2, 1, True, False),   # 3D with 1..3 channels: one zero-padded quad

@@ -116,7 +116,7 @@ bad = 0
 for case in range(cases):
     d = rng.choice([2, 2, 3])
     C = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 31, 32, 33, 48, 70] if d == 2 else [1, 2, 3, 4, 5, 6, 8, 12, 16, 17, 24, 40])
-    N = rng.choice([1, 2, 3, 5])
+    N = rng.choice([1, 2, 3, 5, 8, 16])       # (8, 16: the XCD-aware workgroup order of the tiled point kernels)
     sp = tuple(rng.choice([2, 3, 5, 16, 17, 18, 33, 40]) for _ in range(d)) if d == 2 else \
         tuple(rng.choice([2, 3, 5, 8, 9, 16]) for _ in range(d))
     P = rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 3001, 5000, 20000])
