@@ -118,6 +118,42 @@ static __global__ __launch_bounds__(256) void pack_channels_last(const float *__
     }
 }
 
+// XCD-aware order of the point kernels' workgroups (a speed choice only: every order computes the same values).  The
+// launch is (ceil(P/256), N) workgroups; the dispatcher deals them round-robin over the 8 XCDs (MI355X_MICROARCH.md,
+// workgroup dispatch: blocks b and b + 8 share one), so in launch order all 8 XCDs work on table n at the same time and
+// every XCD pulls every table through its own L2 -- 8 x 64 MiB of fabric reads per stage at BASELINE configs[1], and a
+// table line is re-used by an eighth of the table's samples only.  With N a multiple of 8 the workgroups that share an XCD
+// take the tables n = x, x + 8, ... one after the other instead: a table passes through ONE L2, where its 32 768 lines are
+// each wanted by all 2^20 points' gathers.  (The channels-last table of one n, 4 MiB at configs[1], is as large as an L2.)
+// The backward point kernels gain 0.05 ms each at configs[1]; the forward one LOSES 0.02 (16 output rows per table: 128
+// write streams in flight instead of 16) and keeps the launch order (XCD = false).  profiles/round4_ablation.txt section 12.
+#ifndef CS_XCD_TABLES
+#define CS_XCD_TABLES 1
+#endif
+#ifndef CS_XCD_STAGGER
+#define CS_XCD_STAGGER 1
+#endif
+struct PBlk {
+    int x, n;      // which 256 points, which table
+};
+template <bool XCD = true>
+__device__ __forceinline__ PBlk pblk() {
+    PBlk b{(int)blockIdx.x, (int)blockIdx.y};
+#if CS_XCD_TABLES
+    if (XCD && (gridDim.y & 7u) == 0 && (uint64_t)gridDim.x * gridDim.y < (1ull << 31)) {
+        const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x, j = l >> 3, t = j / gridDim.x;
+        b.x = (int)(j - t * gridDim.x);
+        b.n = (int)((l & 7u) + 8u * t);
+#if CS_XCD_STAGGER
+        // ... and each of the 8 groups starts its tables an eighth of the points further on: the 8 tables in flight are then
+        // read and written at different p (without this the gain depends on the device: section 12)
+        b.x = (int)(((uint32_t)b.x + (l & 7u) * ((gridDim.x + 7u) >> 3)) % gridDim.x);
+#endif
+    }
+#endif
+    return b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan kernels
 // ------------------------------------------------------------------------------------------------
@@ -292,41 +328,6 @@ __device__ __forceinline__ float ld_stream(const T *p) { return stream_load(p); 
 // ---- 16-bit streams (float16 / bfloat16 elements, fp32 arithmetic) --------------------------------------------
 // When the channel rows are dword aligned and P is even (Flags::pair16) they move two samples per dword, straight
 // between HBM and the wave's LDS rows (StreamRegs / store_rows16 below); otherwise element by element.
-// XCD-aware order of the point kernels' workgroups (a speed choice only: every order computes the same values).  The
-// launch is (ceil(P/256), N) workgroups; the dispatcher deals them round-robin over the 8 XCDs (MI355X_MICROARCH.md,
-// workgroup dispatch: blocks b and b + 8 share one), so in launch order all 8 XCDs work on table n at the same time and
-// every XCD pulls every table through its own L2 -- 8 x 64 MiB of fabric reads per stage at BASELINE configs[1], and a
-// table line is re-used by an eighth of the table's samples only.  With N a multiple of 8 the workgroups that share an XCD
-// take the tables n = x, x + 8, ... one after the other instead: a table passes through ONE L2, where its 32 768 lines are
-// each wanted by all 2^20 points' gathers.  (The channels-last table of one n, 4 MiB at configs[1], is as large as an L2.)
-// The backward point kernels gain 0.05 ms each at configs[1]; the forward one LOSES 0.02 (16 output rows per table: 128
-// write streams in flight instead of 16) and keeps the launch order (XCD = false).  profiles/round4_ablation.txt section 12.
-#ifndef CS_XCD_TABLES
-#define CS_XCD_TABLES 1
-#endif
-#ifndef CS_XCD_STAGGER
-#define CS_XCD_STAGGER 1
-#endif
-struct PBlk {
-    int x, n;      // which 256 points, which table
-};
-template <bool XCD = true>
-__device__ __forceinline__ PBlk pblk() {
-    PBlk b{(int)blockIdx.x, (int)blockIdx.y};
-#if CS_XCD_TABLES
-    if (XCD && (gridDim.y & 7u) == 0 && (uint64_t)gridDim.x * gridDim.y < (1ull << 31)) {
-        const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x, j = l >> 3, t = j / gridDim.x;
-        b.x = (int)(j - t * gridDim.x);
-        b.n = (int)((l & 7u) + 8u * t);
-#if CS_XCD_STAGGER
-        // ... and each of the 8 groups starts its tables an eighth of the points further on: the 8 tables in flight are then
-        // read and written at different p (their rows are a power of two apart: at equal p they meet in the same HBM channels)
-        b.x = (int)(((uint32_t)b.x + (l & 7u) * ((gridDim.x + 7u) >> 3)) % gridDim.x);
-#endif
-    }
-#endif
-    return b;
-}
 // the wave's first sample and how many of its 64 exist
 template <bool XCD = true>
 __device__ __forceinline__ int64_t wave_p0() { return (int64_t)pblk<XCD>().x * 256 + (threadIdx.x & ~63); }

@@ -8,7 +8,11 @@ if [ "$1" = build ]; then
   # UNIT (default cs_abi) is recompiled with the extra flags and linked with the other units' objects of the default build
   U=${UNIT:-cs_abi}
   python -m cosinesampler_amd.build > /dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS--fno-slp-vectorize} $3 \
+  # the unit's own flags of the default build (cosinesampler_amd/build.py EXTRA_FLAGS): a variant must differ from the default
+  # library by its -D flags ONLY (round 4: variants of cs_abi were built with -fno-slp-vectorize, which the default cs_abi is
+  # not, and lost 2.4 % of the drawn-points step to that alone -- profiles/round4_ablation.txt section 12)
+  UFLAGS=$(python -c "from cosinesampler_amd import build; print(' '.join(build.COMMON_FLAGS + build.EXTRA_FLAGS.get('$U.hip', [])))")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS-$UFLAGS} $3 \
       -o $R/cosinesampler_amd/lib/obj/alt_$2_$U.o $R/cosinesampler_amd/csrc/$U.hip
   OBJS=""
   for u in cs_abi cs_coherent cs_coherent_sum cs_sort; do
