@@ -125,8 +125,9 @@ static __global__ __launch_bounds__(256) void pack_channels_last(const float *__
 // table line is re-used by an eighth of the table's samples only.  With N a multiple of 8 the workgroups that share an XCD
 // take the tables n = x, x + 8, ... one after the other instead: a table passes through ONE L2, where its 32 768 lines are
 // each wanted by all 2^20 points' gathers.  (The channels-last table of one n, 4 MiB at configs[1], is as large as an L2.)
-// The backward point kernels gain 0.05 ms each at configs[1]; the forward one LOSES 0.02 (16 output rows per table: 128
-// write streams in flight instead of 16) and keeps the launch order (XCD = false).  profiles/round4_ablation.txt section 12.
+// The first / second backward stages gain 0.04 / 0.03 ms at configs[1] (-1.5 % of the step); the forward point kernel LOSES
+// 0.02 (16 output rows per table: 128 write streams in flight instead of 16) and keeps the launch order (XCD = false).
+// profiles/round4_ablation.txt section 12.
 #ifndef CS_XCD_TABLES
 #define CS_XCD_TABLES 1
 #endif
