@@ -77,6 +77,7 @@ int make_problem(Problem &pb, int dim, int64_t N, int64_t C, int64_t D, int64_t 
     pb.d.go_ns = pb.d.ho_ns = pb.d.out_ns = C * P;   // contiguous streams unless the entry point is given a layout
     pb.d.grid_ns = grid_bc ? 0 : P;
     pb.d.nsum = 0;            // set by use_nsum3() where a 3D stage runs in the summing mode
+    pb.d.xcd = 0;             // set by prepare() for the tiled 2D backward point kernels
     pb.f.pad = padding_mode;
     pb.f.align = align_corners ? 1 : 0;
     pb.f.multicell = multicell ? 1 : 0;
@@ -473,6 +474,7 @@ struct Prepared {
     const float *icl;
     tl::Plan plan;
     bool plan_is_callers;   // it outlives this call: worth leaving the sorted gOut copy in it
+    Dims d;                 // the problem as the backward point kernels get it (Dims::xcd decided here)
 };
 
 // resolve input_cl / plan: use the caller's, or build into the workspace
@@ -489,6 +491,7 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
         out.icl = buf;
     }
     out.plan_is_callers = false;
+    out.d = pb.d;
     if (stage == CS_STAGE_FORWARD) return CS_OK;
     PlanLayout L = plan_layout(pb.d.N, pb.d.C, pb.d.size[1], pb.d.size[0], pb.d.P);
     if (plan) {
@@ -501,6 +504,9 @@ int prepare(const Problem &pb, int stage, const float *input, const float *grid,
         if (rc) return rc;
         out.plan = plan_view(L, blob);
     }
+    // the XCD-aware workgroup order of the backward point kernels (cs_tiled.cuh pblk): where it was measured to pay -- fp32
+    // streams, tile walkers (not the crowded-table path); the kernels fall back by themselves when N does not divide
+    out.d.xcd = (pb.sdt == 0 && !out.plan.dense) ? 1 : 0;
     return CS_OK;
 }
 
@@ -599,7 +605,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     }
     if (!grad_input) {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
-                                          (const ST *)gOut, pr.icl, grid, offset, nullptr, grad_grid, pb.d, pb.f))));
+                                          (const ST *)gOut, pr.icl, grid, offset, nullptr, grad_grid, pr.d, pb.f))));
         return launch_status();
     }
     // with grad_input: the same point kernel also leaves the fat rows [gOut | W_a]; the tile walkers add them up
@@ -608,7 +614,7 @@ int tiled_backward(const Problem &pb, const float *gOut, const float *input, con
     rc = walker_target(pb, grad_input);
     if (rc) return rc;
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_backward<KERNEL, CQ, true, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 4), pb.stream>>>(
-                                      (const ST *)gOut, pr.icl, grid, offset, fat, grad_grid, pb.d, pb.f))));
+                                      (const ST *)gOut, pr.icl, grid, offset, fat, grad_grid, pr.d, pb.f))));
     rc = launch_status();
     if (rc) return rc;
     // a caller's plan outlives this call: when asked, leave the sorted copy of grad_output in it for later stages' walkers
@@ -656,7 +662,7 @@ int tiled_bb(const Problem &pb, const float *cI, const float *cG, const float *i
     const size_t shm = q_lds(tl::row1((int)cpad(pb.d.C)), 12);
 #define CS_TILED_BB(HAS_CI, ROWS)                                                                                      \
     CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bb<KERNEL, CQ, HAS_CI, ROWS, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>( \
-                                      cIcl, cG, pr.icl, grid, (const ST *)gOut, offset, fat, gGrid, (ST *)ggOut, pb.d, pb.f))))
+                                      cIcl, cG, pr.icl, grid, (const ST *)gOut, offset, fat, gGrid, (ST *)ggOut, pr.d, pb.f))))
     if (!gInput) { if (cIcl) { CS_TILED_BB(true, 0); } else { CS_TILED_BB(false, 0); } }
     else if (lean) { if (cIcl) { CS_TILED_BB(true, 2); } else { CS_TILED_BB(false, 2); } }
     else { if (cIcl) { CS_TILED_BB(true, 1); } else { CS_TILED_BB(false, 1); } }
@@ -695,7 +701,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
             rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, true, ST>, shm);
             if (!rc) tl::point_bbb<KERNEL, CQ, true, true, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f);
+                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pr.d, pb.f);
         }));
         if (rc) return rc;
         rc = launch_status();
@@ -707,7 +713,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, {
             rc = allow_lds(tl::point_bbb<KERNEL, CQ, true, false, ST>, shm);
             if (!rc) tl::point_bbb<KERNEL, CQ, true, false, ST><<<point_grid(pb), kBlock, shm, pb.stream>>>(
-                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f);
+                         pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pr.d, pb.f);
         }));
         if (rc) return rc;
         rc = launch_status();
@@ -716,7 +722,7 @@ int tiled_bbb(const Problem &pb, const float *input, const float *grid, const fl
         return launch_tile_scatter<1>(pb, pr.plan, fat, gInput);
     } else {
         CS_DISPATCH_KERNEL(pb.kernel, CS_DISPATCH_CQT(pb.d.C, (tl::point_bbb<KERNEL, CQ, false, false, ST><<<point_grid(pb), kBlock, q_lds(tl::row1((int)cpad(pb.d.C)), 0), pb.stream>>>(
-                                          pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pb.d, pb.f))));
+                                          pr.icl, grid, (const ST *)gOut, cG, hG, (const ST *)hO, offset, fat, (ST *)ggOut, pr.d, pb.f))));
         rc = launch_status();
         if (rc) return rc;
         if (g_leave && pr.plan_is_callers && !pr.plan.dense) return launch_tile_scatter<0, true>(pb, pr.plan, fat, gInput);

@@ -38,6 +38,7 @@ struct Dims {
     // CS_SUM_OVER_N on the channels-last point kernels (cs_points_cl.cuh, 3D): non-zero = one lane owns a POINT for all N
     // tables and the per-point results leave summed over them (the streams then have no n: go_ns = ho_ns = grid_ns = 0)
     int nsum;
+    int xcd;       // the tiled 2D backward point kernels take their workgroups in the XCD-aware order (cs_tiled.cuh pblk)
     __host__ __device__ __forceinline__ int64_t gpt(int n, int64_t p) const { return (int64_t)n * grid_ns + p; }
 };
 

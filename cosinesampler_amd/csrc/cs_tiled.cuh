@@ -118,16 +118,15 @@ static __global__ __launch_bounds__(256) void pack_channels_last(const float *__
     }
 }
 
-// XCD-aware order of the point kernels' workgroups (a speed choice only: every order computes the same values).  The
-// launch is (ceil(P/256), N) workgroups; the dispatcher deals them round-robin over the 8 XCDs (MI355X_MICROARCH.md,
-// workgroup dispatch: blocks b and b + 8 share one), so in launch order all 8 XCDs work on table n at the same time and
-// every XCD pulls every table through its own L2 -- 8 x 64 MiB of fabric reads per stage at BASELINE configs[1], and a
-// table line is re-used by an eighth of the table's samples only.  With N a multiple of 8 the workgroups that share an XCD
-// take the tables n = x, x + 8, ... one after the other instead: a table passes through ONE L2, where its 32 768 lines are
-// each wanted by all 2^20 points' gathers.  (The channels-last table of one n, 4 MiB at configs[1], is as large as an L2.)
-// The first / second backward stages gain 0.04 / 0.03 ms at configs[1] (-1.5 % of the step); the forward point kernel LOSES
-// 0.02 (16 output rows per table: 128 write streams in flight instead of 16) and keeps the launch order (XCD = false).
-// profiles/round4_ablation.txt section 12.
+// XCD-aware order of the backward point kernels' workgroups (a speed choice only: every order computes the same values;
+// Dims::xcd, set by the host where it was measured to pay).  The launch is (ceil(P/256), N) workgroups, dealt round-robin
+// over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch: blocks b and b + 8 share one): in launch order the whole chip
+// works on table n, then on n + 1.  With Dims::xcd the XCDs form CS_XCD_GROUPS groups, each owning whole tables (n = g,
+// g + G, ... one after the other) and starting a G-th of the points further on than the last, so that G tables are in flight
+// at different p.  BASELINE configs[1], fp32 streams: first / second backward -0.05 / -0.04 ms, the step -1.8 % -- with 2, 4
+// or 8 groups alike, so it is not the table meeting fewer L2s that pays (profiles/round4_ablation.txt section 12, 15).
+// Where it LOSES and stays off: the forward point kernel (-0.02 ms: it has nothing but its 16 output rows per table to
+// stream), 16-bit streams (+5-7 % on the step) and the crowded-table path (+2-3 %).
 #ifndef CS_XCD_TABLES
 #define CS_XCD_TABLES 1
 #endif
@@ -137,18 +136,22 @@ static __global__ __launch_bounds__(256) void pack_channels_last(const float *__
 struct PBlk {
     int x, n;      // which 256 points, which table
 };
-template <bool XCD = true>
-__device__ __forceinline__ PBlk pblk() {
+#ifndef CS_XCD_GROUPS
+#define CS_XCD_GROUPS 2       // tables in flight: the XCDs form this many groups, each group owns whole tables (2, 4 or 8: measured alike)
+#endif
+__device__ __forceinline__ PBlk pblk(int on) {      // on: Dims::xcd, the host's choice (0: the launch order)
     PBlk b{(int)blockIdx.x, (int)blockIdx.y};
 #if CS_XCD_TABLES
-    if (XCD && (gridDim.y & 7u) == 0 && (uint64_t)gridDim.x * gridDim.y < (1ull << 31)) {
-        const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x, j = l >> 3, t = j / gridDim.x;
-        b.x = (int)(j - t * gridDim.x);
-        b.n = (int)((l & 7u) + 8u * t);
+    constexpr uint32_t G = CS_XCD_GROUPS, M = 8 / G;      // M XCDs per group
+    if (on && G > 1 && (gridDim.y % G) == 0 && (uint64_t)gridDim.x * gridDim.y < (1ull << 31)) {
+        const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x, xcd = l & 7u, g = xcd % G, r = xcd / G;
+        const uint32_t k = (l >> 3) * M + r, t = k / gridDim.x;      // the group's k-th workgroup: table t of the group
+        b.x = (int)(k - t * gridDim.x);
+        b.n = (int)(g + G * t);
 #if CS_XCD_STAGGER
-        // ... and each of the 8 groups starts its tables an eighth of the points further on: the 8 tables in flight are then
+        // ... and each of the groups starts its tables a G-th of the points further on: the tables in flight are then
         // read and written at different p (without this the gain depends on the device: section 12)
-        b.x = (int)(((uint32_t)b.x + (l & 7u) * ((gridDim.x + 7u) >> 3)) % gridDim.x);
+        b.x = (int)(((uint32_t)b.x + g * ((gridDim.x + G - 1) / G)) % gridDim.x);
 #endif
     }
 #endif
@@ -330,11 +333,9 @@ __device__ __forceinline__ float ld_stream(const T *p) { return stream_load(p); 
 // When the channel rows are dword aligned and P is even (Flags::pair16) they move two samples per dword, straight
 // between HBM and the wave's LDS rows (StreamRegs / store_rows16 below); otherwise element by element.
 // the wave's first sample and how many of its 64 exist
-template <bool XCD = true>
-__device__ __forceinline__ int64_t wave_p0() { return (int64_t)pblk<XCD>().x * 256 + (threadIdx.x & ~63); }
-template <bool XCD = true>
-__device__ __forceinline__ int wave_nlive(int64_t P) {
-    const int64_t r = P - wave_p0<XCD>();
+__device__ __forceinline__ int64_t wave_p0(int xcd) { return (int64_t)pblk(xcd).x * 256 + (threadIdx.x & ~63); }
+__device__ __forceinline__ int wave_nlive(int64_t P, int xcd) {
+    const int64_t r = P - wave_p0(xcd);
     return r <= 0 ? 0 : (r > 64 ? 64 : (int)r);
 }
 template <typename T>
@@ -362,7 +363,7 @@ template <int KERNEL>
 __device__ __forceinline__ void point_phase1(float *rec, const float *grid, const float *offset, const Dims &d,
                                              const Flags &f, int align) {
     const int lane = threadIdx.x & 63;
-    const PBlk wb = pblk<false>();        // (the forward stage only: see pblk)
+    const PBlk wb = pblk(0);        // (the forward stage only: see pblk)
     const int n = wb.n;
     int64_t p = (int64_t)wb.x * 256 + threadIdx.x;
     if (p >= d.P) p = d.P - 1;
@@ -397,7 +398,7 @@ struct QuadSample {
         const int per = 64 / CQ;
         sl = sub * per + lane / CQ;
         q = lane % CQ;
-        p = wave_p0<false>() + sl;
+        p = wave_p0(0) + sl;
         live = p < d.P;
         const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
 #pragma unroll
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
     float *rec = lds + (threadIdx.x >> 6) * REC_FLOATS;
     point_phase1<KERNEL>(rec, grid, offset, d, f, 1);   // 2D forward: align_corners = 1 (2d.cu:307-308)
     __syncthreads();
-    const int n = pblk<false>().n;
+    const int n = pblk(0).n;
     const float4 *tab = reinterpret_cast<const float4 *>(icl + (int64_t)n * d.vol * C);
     ST *obase = out + (int64_t)n * d.out_ns;   // out_ns: d.C * d.P for a contiguous stream (d.C: the caller's channel count)
     float *ot = lds + 4 * REC_FLOATS + (threadIdx.x >> 6) * (C * OUT_LD);   // this wave's [C][64] result tile
@@ -477,12 +478,12 @@ __global__ __launch_bounds__(256) void point_forward(const float *__restrict__ i
         ot[(4 * qs.q + 3) * OUT_LD + qs.sl] = acc.w;
     }
     __syncthreads();
-    const int64_t p = (int64_t)pblk<false>().x * 256 + threadIdx.x;
+    const int64_t p = (int64_t)pblk(0).x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if constexpr (sizeof(ST) == 2) if (f.pair16) {   // lanes 0..31: channel c, lanes 32..63: channel c+1 (store_rows16)
         const int L = lane & 31, up = lane >> 5;
-        if (2 * L >= wave_nlive<false>(d.P)) return;
-        ST *row = obase + wave_p0<false>() + 2 * L;
+        if (2 * L >= wave_nlive(d.P, 0)) return;
+        ST *row = obase + wave_p0(0) + 2 * L;
 #pragma unroll
         for (int c0 = 0; c0 < C; c0 += 2) {
             const int c = c0 + up;
@@ -514,7 +515,7 @@ struct Sample2 {
     // stream loads in between, so that one memory round trip covers both (a wave used to wait for its coordinates,
     // work out the geometry and only then ask for the streams).
     __device__ __forceinline__ void begin(const float *grid, const Dims &d) {
-        const PBlk wb = pblk();
+        const PBlk wb = pblk(d.xcd);
         n = wb.n;
         int64_t pp = (int64_t)wb.x * blockDim.x + threadIdx.x;
         live = pp < d.P;
@@ -595,8 +596,8 @@ struct StreamRegs {
         if constexpr (sizeof(T) == 2) {
             if (pair16) {
                 const int lane = threadIdx.x & 63, L = lane & 31, up = lane >> 5;
-                const bool live = 2 * L < wave_nlive(P);
-                const T *base = chan0_n + (live ? wave_p0() + 2 * L : 0);
+                const bool live = 2 * L < wave_nlive(P, 0);      // (16-bit streams: always the launch order, Dims::xcd)
+                const T *base = chan0_n + (live ? wave_p0(0) + 2 * L : 0);
 #pragma unroll
                 for (int i = 0; i < 2 * CQ; ++i) {
                     const int c = 2 * i + up;
@@ -615,7 +616,7 @@ struct StreamRegs {
         if constexpr (sizeof(T) == 2) {
             if (pair16) {
                 const int L = lane & 31, up = lane >> 5;
-                const bool live = 2 * L < wave_nlive(P);
+                const bool live = 2 * L < wave_nlive(P, 0);
                 float *r0 = stage + off + (2 * L) * stride + up;
 #pragma unroll
                 for (int i = 0; i < 2 * CQ; ++i) {
@@ -668,7 +669,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *uniform_
 template <int STRIDE>
 __device__ __forceinline__ void flush_rows(const float *stage, float *fat, int n, const Dims &d) {
     const int lane = threadIdx.x & 63;
-    const int64_t p0 = wave_p0();     // first point of this wave
+    const int64_t p0 = wave_p0(d.xcd);     // first point of this wave
     if (p0 >= d.P) return;
     const int nlive = (int)min((int64_t)64, d.P - p0);
     const __amdgpu_buffer_rsrc_t dst = rows_rsrc(fat + ((int64_t)n * d.P + p0) * STRIDE);
@@ -726,7 +727,7 @@ template <int CQ, typename T>
 __device__ __forceinline__ void q_store_rows(const float *stage, int stride, T *chan0_n, int64_t p, int64_t P, bool live,
                                              int C, bool pair16) {
     if constexpr (sizeof(T) == 2) if (pair16) {
-        store_rows16<CQ>(stage, stride, chan0_n + wave_p0(), P, wave_nlive(P), C);
+        store_rows16<CQ>(stage, stride, chan0_n + wave_p0(0), P, wave_nlive(P, 0), C);
         return;
     }
     if (!live) return;
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(256) void point_bb(const float *__restrict__ cIcl, 
         }
         *reinterpret_cast<float4 *>(row + C) = make_float4(Dm[0], Dm[1], Dm[2], Dm[3]);
         if (ROWS == 2 && sm.live) {
-            const int64_t s0w = (int64_t)sm.n * d.P + wave_p0();          // the wave's first sample: uniform
+            const int64_t s0w = (int64_t)sm.n * d.P + wave_p0(d.xcd);          // the wave's first sample: uniform
             st_row16<CS_ROWS_AUX>(rows_rsrc(fat + s0w * 4), (uint32_t)(threadIdx.x & 63) * 16u, make_float4(Dm[0], Dm[1], Dm[2], Dm[3]));
         }
         q_put_nodes(rec, sm);

@@ -142,12 +142,14 @@ def test_tiled_path_matches_cpu_oracle(C, ke, pad, align, mc, shared):
 
 
 @pytest.mark.parametrize("N,C,P,sp,crowded", [(8, 16, 3001, (37, 50), False), (16, 4, 1029, (20, 33), False), (24, 8, 700, (18, 18), False),
-                                               (8, 4, 20000, (9, 12), True), (16, 16, 255, (37, 50), False)])
+                                               (8, 4, 20000, (9, 12), True), (16, 16, 255, (37, 50), False), (2, 8, 257, (37, 50), False),
+                                               (6, 16, 2303, (20, 33), False)])
 def test_xcd_aware_workgroup_order_of_the_point_kernels(N, C, P, sp, crowded):
-    """With N a multiple of 8 the tiled point kernels (backward stages) take their workgroups in another order -- the 8 groups of
-    workgroups that share an XCD own the tables n = x, x + 8, .., each group starting at its own p (cs_tiled.cuh pblk): a speed
-    choice that must not change a value.  Ragged P (a last workgroup with few points, fewer workgroups than XCDs), the tile
-    walkers and the crowded-table path, every stage against the oracle."""
+    """With fp32 streams and an even N the tiled backward point kernels take their workgroups in another order -- the XCDs
+    form two groups that own whole tables (n = g, g + 2, ..), the second group starting half the points further on
+    (cs_tiled.cuh pblk, Dims::xcd): a speed choice that must not change a value.  Ragged P (a last workgroup with few points,
+    fewer workgroups than XCDs), the tile walkers and the crowded-table path (which keeps the launch order), every stage
+    against the oracle.  (Most 2D cases of this file with an even N run in that order too.)"""
     ke, pad, align, mc = 0, 0, True, True
     t = _case(2, N, C, sp, P, seed=8800 + N + C, spread=1.1)
     off = offsets(N, mc)
