@@ -382,7 +382,8 @@ def _call(stage, dim, ptrs, shape, P, padding_mode, align_corners, kernel, multi
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
         # coherent points (CS_POINTS_COHERENT): the 2D fast path reads the table through on-chip windows and needs no plan
-        # (sum_n: the summing kernels ARE coherent-points kernels; the caller has decided)
+        # (sum_n in 2D: the summing kernels ARE coherent-points kernels, the caller has decided; in 3D the summing mode runs
+        # on the plain op's point kernels and scatter -- plan and all)
         coherent = dim == 2 and bool(sum_n or (grid is not None and _order_is_coherent(
             ctx, lib, grid, shape, P, padding_mode, align_corners, multicell, stream)))
         if sum_n:
@@ -886,10 +887,10 @@ def bbb_fused(input, grid, grad_output, grad_out_grid, grad_out_ggrid, grad_out_
 # features = sampler(cells, grid.repeat(N,1,1,1)).sum(0) (reference test/test_2d.py:38, :51): one set of points, and -- in
 # every derivative the caller takes -- one cotangent for all N tables and results that are summed over them.  These four
 # functions take and return the n-free tensors ((1,C,..,P) streams, (1,..,P,dim) grid-shaped); input-shaped gradients stay
-# (N,C,H,W).  Where the summing kernels apply (2D fast path, fp32, zeros padding with align_corners, N > 1, C <= 32) they run
-# as ONE kernel per stage that never materialises an (N,C,P) stream; anywhere else the same values come from the plain op
-# on expanded inputs followed by torch sums.
-# The summing kernels walk the points in cell order.  Points in the order they were DRAWN are put into that order INSIDE the
+# (N,C,H,W).  Where the summing kernels apply (2D fast path, fp32, zeros padding with align_corners, N > 1, C <= 32; 3D:
+# C <= 16, fp32, every padding mode -- cs_sum_over_n_supported) no (N,C,P) stream is ever materialised; anywhere else the
+# same values come from the plain op on expanded inputs followed by torch sums.
+# The 2D summing kernels walk the points in cell order.  Points in the order they were DRAWN are put into that order INSIDE the
 # op (round 4): with one set of points for all N tables every per-point tensor is N times smaller than the plain op's --
 # (1,C,P) cotangents and results, 64 MiB where the plain op has 1 GiB -- so sorting the points once per step
 # (cs2d_sort_points: 0.3 ms for 2^20) and carrying the cotangents into that order and the results back with index
