@@ -5,18 +5,22 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
-  # UNIT (default cs_abi) is recompiled with the extra flags and linked with the other units' objects of the default build
-  U=${UNIT:-cs_abi}
+  # UNIT: the unit(s) recompiled with the extra flags (default cs_abi; several separated by blanks), linked with the other
+  # units' objects of the default build
   python -m cosinesampler_amd.build > /dev/null
-  # the unit's own flags of the default build (cosinesampler_amd/build.py EXTRA_FLAGS): a variant must differ from the default
-  # library by its -D flags ONLY (round 4: variants of cs_abi were built with -fno-slp-vectorize, which the default cs_abi is
-  # not, and lost 2.4 % of the drawn-points step to that alone -- profiles/round4_ablation.txt section 12)
-  UFLAGS=$(python -c "from cosinesampler_amd import build; print(' '.join(build.COMMON_FLAGS + build.EXTRA_FLAGS.get('$U.hip', [])))")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS-$UFLAGS} $3 \
-      -o $R/cosinesampler_amd/lib/obj/alt_$2_$U.o $R/cosinesampler_amd/csrc/$U.hip
   OBJS=""
   for u in cs_abi cs_coherent cs_coherent_sum cs_sort; do
-    if [ $u = $U ]; then OBJS="$OBJS $R/cosinesampler_amd/lib/obj/alt_$2_$U.o"; else OBJS="$OBJS $R/cosinesampler_amd/lib/obj/$u.o"; fi
+    case " ${UNIT:-cs_abi} " in
+      *" $u "*)
+        # the unit's own flags of the default build (cosinesampler_amd/build.py EXTRA_FLAGS): a variant must differ from the
+        # default library by its -D flags ONLY (round 4: variants of cs_abi were built with -fno-slp-vectorize, which the
+        # default cs_abi is not, and lost 2.4 % of the drawn-points step to that alone -- profiles/round4_ablation.txt section 12)
+        UFLAGS=$(python -c "from cosinesampler_amd import build; print(' '.join(build.COMMON_FLAGS + build.EXTRA_FLAGS.get('$u.hip', [])))" 2>/dev/null)
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function ${BASEFLAGS-$UFLAGS} $3 \
+            -o $R/cosinesampler_amd/lib/obj/alt_$2_$u.o $R/cosinesampler_amd/csrc/$u.hip
+        OBJS="$OBJS $R/cosinesampler_amd/lib/obj/alt_$2_$u.o" ;;
+      *) OBJS="$OBJS $R/cosinesampler_amd/lib/obj/$u.o" ;;
+    esac
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$R/cosinesampler_amd/csrc/exports.map \
       -o $R/cosinesampler_amd/lib/alt_$2.so $OBJS
