@@ -20,10 +20,13 @@ torch.manual_seed(1)
 gOut = torch.randn(N, C, 1, P, device=dev); hO = torch.randn(N, C, 1, P, device=dev)
 cG = torch.randn(N, 1, P, 2, device=dev); hG = torch.randn(N, 1, P, 2, device=dev)
 off = multicell_offset(N, True, dev)
-if os.environ.get("CS_CHUNKS") or os.environ.get("CS_WPB"):
+if os.environ.get("CS_CHUNKS") or os.environ.get("CS_WPB") or os.environ.get("CS_ABLATE"):
     f, b, bb, bbb = (int(x) for x in os.environ.get("CS_CHUNKS", "4,6,6,6").split(","))
     wpb = int(os.environ.get("CS_WPB", "1"))           # waves per workgroup (1..4)
-    assert ops._lib.load().cs_debug_coherent_tuning(f | b << 8 | bb << 16 | bbb << 24, wpb << 4) == 1, "needs COSINESAMPLER_DEBUG=1"
+    # CS_ABLATE: parts of the kernels switched off (results wrong; only in -DCS_COH_DEBUG builds of cs_coherent): 1 no
+    # scatter-reduce, 2 no accumulator-window flush, 4 no products, 1024 no table-window loads, 2048 no scatter operands to LDS
+    abl = int(os.environ.get("CS_ABLATE", "0"))
+    assert ops._lib.load().cs_debug_coherent_tuning(f | b << 8 | bb << 16 | bbb << 24, wpb << 4 | abl) == 1, "needs COSINESAMPLER_DEBUG=1"
 
 
 def step(ev=None):
@@ -59,5 +62,5 @@ for _ in range(steps):
     step(ev)
 torch.cuda.synchronize()
 st = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) for i in range(4)]
-print("wpb %s chunks %-12s step %.3f ms | forward %.3f  backward %.3f  backward_backward %.3f  bbb_fused %.3f"
-      % (os.environ.get("CS_WPB", "1"), os.environ.get("CS_CHUNKS", "default"), ms, *st), flush=True)
+print("ablate %s wpb %s chunks %-12s step %.3f ms | forward %.3f  backward %.3f  backward_backward %.3f  bbb_fused %.3f"
+      % (os.environ.get("CS_ABLATE", "0"), os.environ.get("CS_WPB", "1"), os.environ.get("CS_CHUNKS", "default"), ms, *st), flush=True)
